@@ -1,0 +1,148 @@
+/*
+ * rrt.h -- C ABI of the MI355X-native per-pixel hot path of conor722/rust-ray-tracer.
+ *
+ * The reference has no FFI; its natural seam is `Scene::draw_scene(&mut self, rt: RayTracer)`
+ * (src/scene/engine.rs:186) called from `main` (src/main.rs:68-74), one level above
+ * `RayTracer::get_ray_colour` (src/scene/raytracer.rs:29).  This header is what a Rust
+ * `extern "C"` block for that seam binds (see INTEGRATION.md for the binding a maintainer adds).
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types.  Every function returns RRT_OK (0) or a
+ * negative rrt_status; nothing aborts or unwinds across the boundary (the reference panics instead:
+ * main.rs:24,28; utils.rs:61,85,170,184,193,222,275,347-349).  All input pointers are borrowed for the
+ * duration of the call only; the library copies what it keeps.  One caller thread per handle.
+ *
+ * There is NO CPU fallback in this library: every compute entry point runs hand-written HIP kernels on
+ * gfx950 and fails with RRT_ERR_NO_DEVICE / RRT_ERR_HIP when no GPU is usable.
+ */
+#ifndef RRT_H
+#define RRT_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    RRT_OK = 0,
+    RRT_ERR_INVALID_ARG = -1,
+    RRT_ERR_HIP = -2,          /* a HIP runtime call failed; rrt_last_error_detail() has the text */
+    RRT_ERR_OOM = -3,
+    RRT_ERR_IO = -4,           /* "Could not read file" (main.rs:28, utils.rs:171, 346-347) */
+    RRT_ERR_PARSE = -5,        /* any `expect`/`unwrap` failure of utils.rs (bad number, missing vertex, ...) */
+    RRT_ERR_DEPTH = -6,        /* octree deeper than RRT_MAX_OCTREE_DEPTH (e.g. duplicate triangles, octree.rs:79-92) */
+    RRT_ERR_NO_DEVICE = -7,
+    RRT_ERR_UNSUPPORTED = -8   /* e.g. a texture format the build-owned decoder does not read */
+} rrt_status;
+
+#define RRT_MAX_OCTREE_DEPTH 40
+
+/* == Vector3d, src/scene/engine.rs:9-14 */
+typedef struct { double x, y, z; } rrt_vec3;
+
+/* == Light, src/scene/entities.rs:5-9.  kind: 0 Ambient{intensity}; 1 Point{intensity, position=v};
+ * 2 Directional{intensity, direction=v} */
+typedef struct { uint32_t kind; uint32_t _pad; double intensity; rrt_vec3 v; } rrt_light;
+
+/* == Material, src/scene/material.rs:11-22 (name dropped).  tex/bump index rrt textures; bump = -1 => None */
+typedef struct { rrt_vec3 ka, kd, ks; double ns, kr; int32_t tex, bump; } rrt_material;
+
+/* == Texture, src/scene/entities.rs:86-91: RGB8, row-major, index = width*y + x (raytracer.rs:55) */
+typedef struct { const uint8_t *rgb; uint32_t width, height; } rrt_texture;
+
+/* Render constants that the reference hard-codes; NULL => these defaults. */
+typedef struct {
+    double surface_offset;            /* 1e-4, raytracer.rs:17 */
+    uint32_t max_reflection_depth;    /* 5,    raytracer.rs:20 (<= 8 supported) */
+    uint32_t _pad;
+    double vp_w, vp_h, vp_d;          /* 1,1,1 Viewport::default, engine.rs:113-119 */
+} rrt_options;
+
+typedef struct {
+    uint32_t n_tris, n_tris_in_tree;  /* triangles outside the root AABB are silently dropped, octree.rs:71-73 */
+    uint32_t n_nodes, max_depth;      /* max_depth counts the root as 1 */
+    uint32_t n_mats, n_tex;
+    uint32_t root_own_count, max_own_count;
+} rrt_model_info;
+
+typedef struct {
+    double   kernel_ms;               /* HIP-event time of the last render's trace kernel on its stream */
+    uint32_t width, height;
+    uint64_t rays_primary;            /* 4 * pixels actually traced */
+    uint64_t scene_bytes;             /* bytes resident in HBM for this raytracer (geometry+octree+textures) */
+} rrt_stats;
+
+/* ------------------------------------------------------------------ model = SceneData (scenedata.rs:5-13), host side */
+typedef struct rrt_model rrt_model;
+
+/* parse_obj_file_lines (utils.rs:139-213) on the file at obj_path (read as main.rs:28); "mtllib"/texture names
+ * resolve relative to the .obj's directory (the reference resolves against the cwd; it is run from its root).
+ * Builds the octree incrementally in file order (utils.rs:192-198).  root = {min_x,max_x,min_y,max_y,min_z,max_z},
+ * NULL => Octree::new(-20,20,-20,20,-20,20) (utils.rs:145). */
+int rrt_model_load_obj(const char *obj_path, const double *root, rrt_model **out);
+
+/* For a host that already parsed the scene (the Rust host holds SceneData.triangles in push order):
+ * pos/uv/nrm are [n][3][3] doubles (v1,v2,v3; uv z ignored), mat[n] indexes mats.  Textures are copied. */
+int rrt_model_from_arrays(uint32_t n_tris, const double *pos, const double *uv, const double *nrm, const uint32_t *mat,
+                          uint32_t n_mats, const rrt_material *mats, uint32_t n_tex, const rrt_texture *tex,
+                          const double *root, rrt_model **out);
+void rrt_model_destroy(rrt_model *m);
+
+int rrt_model_get_info(const rrt_model *m, rrt_model_info *out);
+int rrt_model_get_triangles(const rrt_model *m, double *pos, double *uv, double *nrm, uint32_t *mat);   /* any may be NULL */
+int rrt_model_get_materials(const rrt_model *m, rrt_material *out);
+int rrt_model_get_texture(const rrt_model *m, uint32_t index, rrt_texture *out);                        /* borrowed view */
+/* The octree exactly as octree.rs:41-241 builds it, flattened: aabb[n_nodes][6] = min xyz,max xyz;
+ * first_child (0 = leaf, else 8 consecutive ids, octree.rs:226-238); tri_count (octree.rs:75);
+ * own_off[n_nodes+1], own_idx[] = each node's `triangles` Vec in insertion order. */
+int rrt_model_get_octree(const rrt_model *m, double *aabb, uint32_t *first_child, uint32_t *tri_count,
+                         uint32_t *own_off, uint32_t *own_idx);
+
+/* Build-owned baseline-JPEG / PNG decode to RGB8 (stands where `image::ImageReader::open().decode()` does,
+ * utils.rs:345-368).  *rgb is malloc'd; free with rrt_free. */
+int rrt_decode_image_file(const char *path, uint8_t **rgb, uint32_t *width, uint32_t *height);
+void rrt_free(void *p);
+
+/* ------------------------------------------------------------------ raytracer = RayTracer{scene_data,lights,origin} (raytracer.rs:22-26) on one GPU */
+typedef struct rrt_raytracer rrt_raytracer;
+
+/* Uploads the scene once to HBM of HIP device `device`.  opt may be NULL. */
+int rrt_raytracer_create(const rrt_model *m, const rrt_light *lights, uint32_t n_lights, rrt_vec3 origin,
+                         const rrt_options *opt, int device, rrt_raytracer **out);
+void rrt_raytracer_destroy(rrt_raytracer *rt);
+
+/* Scene::draw_scene (engine.rs:186-255) + Canvas::put_pixel (engine.rs:146-158): fills out_fb[width*height]
+ * (host memory), 0x00RRGGBB (entities.rs:32-36), row 0 = top; pixels the reference never writes (row 0, and for
+ * odd sizes row 1 / the last column) are 0 as in Canvas::new (engine.rs:135).  Blocking. */
+int rrt_render(rrt_raytracer *rt, uint32_t width, uint32_t height, uint32_t *out_fb);
+
+/* Same, framebuffer in device memory of rt's device; enqueued on `stream` (hipStream_t, NULL = default), not synchronised. */
+int rrt_render_device(rrt_raytracer *rt, uint32_t width, uint32_t height, void *d_fb, void *stream);
+
+/* Screen-tile partition for N GPUs (one process per GPU): the frame is cut into 8x8-pixel tiles, tile k (row-major)
+ * belongs to rank k % world.  Renders this rank's tiles into d_tiles[rrt_tiles_per_rank][64] (tile-major, device).
+ * After an all-gather of the per-rank buffers (RCCL, done by the caller), rrt_detile_device turns
+ * d_gathered[world][tiles_per_rank][64] into the row-major framebuffer d_fb[width*height]. */
+uint32_t rrt_tiles_per_rank(uint32_t width, uint32_t height, uint32_t world);
+int rrt_render_tiles_device(rrt_raytracer *rt, uint32_t width, uint32_t height, uint32_t rank, uint32_t world,
+                            void *d_tiles, void *stream);
+int rrt_detile_device(rrt_raytracer *rt, uint32_t width, uint32_t height, uint32_t world, const void *d_gathered,
+                      void *d_fb, void *stream);
+
+/* Batched RayTracer::get_ray_colour (raytracer.rs:29): n rays, origins/dirs [n][3] host doubles -> colours[n] 0x00RRGGBB. */
+int rrt_get_ray_colours(rrt_raytracer *rt, uint32_t n, const double *origins, const double *dirs, uint32_t *colours);
+
+/* Batched Ray::intersect_with_octant_with_max_t(octree, 0, max_t) (ray.rs:104-168): hit[n] 0/1, t,u,v [n], tri[n] = index in
+ * push order.  max_t may be NULL (= +inf, ray.rs:96-102). */
+int rrt_intersect_rays(rrt_raytracer *rt, uint32_t n, const double *origins, const double *dirs, const double *max_t,
+                       uint8_t *hit, double *t, double *u, double *v, uint32_t *tri);
+
+int rrt_last_stats(const rrt_raytracer *rt, rrt_stats *out);
+int rrt_device_count(int *count);
+const char *rrt_strerror(int status);
+const char *rrt_last_error_detail(void);   /* thread-local text of the last failure */
+const char *rrt_build_info(void);          /* offload arch, fp-contract mode */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

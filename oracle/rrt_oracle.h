@@ -1,0 +1,74 @@
+/*
+ * rrt_oracle.h -- CPU restatement (plain C, f64) of the reference renderer's per-pixel hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load it, and only as the checker / reported CPU baseline.
+ * The product library (librrt_hip.so) neither links nor calls anything in this directory.
+ *
+ * PARITY STATUS: "parity unpinned by a runnable reference".  The reference is Rust; no Rust toolchain
+ * exists in this image or on the GPU box, and the reference ships no live tests or golden images
+ * (SURVEY.md section 8c).  The oracle is pinned by (a) the still-valid data vectors in the reference's
+ * commented-out octree tests (octree.rs:244-652: child-AABB order/geometry, from_triangle boxes) and
+ * (b) hand-derived known-answer tests, see tests/test_oracle_kat.py.
+ *
+ * Every function cites the reference file:line it follows (paths relative to the reference root).
+ */
+#ifndef RRT_ORACLE_H
+#define RRT_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { double x, y, z; } ovec3;                                   /* engine.rs:9-14 */
+typedef struct { uint32_t kind; uint32_t _pad; double intensity; ovec3 v; } olight;  /* entities.rs:5-9; 0 Ambient, 1 Point(position), 2 Directional(direction) */
+typedef struct { ovec3 ka, kd, ks; double ns, kr; int32_t tex, bump; } omaterial;     /* material.rs:11-22; bump = -1 => None */
+typedef struct { const uint8_t *rgb; uint32_t width, height; } otexture;              /* entities.rs:86-91 */
+
+typedef struct {
+    uint64_t rays_primary, rays_shadow, rays_reflect;
+    uint64_t tri_tests, aabb_tests, nodes_entered, hits_shaded;
+} ocounters;
+
+typedef struct oracle_scene oracle_scene;
+
+/* Build the scene: pushes triangles into the octree in array order (utils.rs:192-198 -> octree.rs:41-52).
+ * pos/uv/nrm are [n][3][3] doubles (v1,v2,v3 each xyz; uv uses x,y only, raytracer.rs:45-50).
+ * root = {min_x,max_x,min_y,max_y,min_z,max_z} as Octree::new (octree.rs:23, utils.rs:145).
+ * Texture pixel data is borrowed: the caller keeps it alive while the scene lives. */
+oracle_scene *oracle_scene_create(uint32_t n_tris, const double *pos, const double *uv, const double *nrm,
+                                  const uint32_t *mat, uint32_t n_mats, const omaterial *mats,
+                                  uint32_t n_tex, const otexture *tex, uint32_t n_lights, const olight *lights,
+                                  ovec3 origin, const double root[6]);
+void oracle_scene_destroy(oracle_scene *s);
+
+/* octree introspection (structure parity with the product's flattened tree) */
+uint32_t oracle_octree_num_nodes(const oracle_scene *s);
+uint32_t oracle_octree_max_depth(const oracle_scene *s);
+/* per node: aabb[6] = min xyz, max xyz; first_child (0 = leaf, else 8 consecutive ids);
+ * tri_count (octree.rs:75); own-list CSR offsets [n_nodes+1]; own-list triangle ids in insertion order. */
+void oracle_octree_export(const oracle_scene *s, double *aabb, uint32_t *first_child, uint32_t *tri_count,
+                          uint32_t *own_off, uint32_t *own_idx);
+uint32_t oracle_octree_own_total(const oracle_scene *s);
+
+/* primitives (for KATs) */
+int oracle_intersect_aabb(ovec3 o, ovec3 d, const double box[6], double *t);                 /* ray.rs:21-54 */
+int oracle_intersect_triangle(ovec3 o, ovec3 d, const double v[9], double *t, double *u, double *vv); /* ray.rs:56-94 */
+int oracle_intersect_scene(const oracle_scene *s, ovec3 o, ovec3 d, double max_t, double *t, double *u,
+                           double *v, uint32_t *tri);                                        /* ray.rs:104-168 */
+uint32_t oracle_get_ray_colour(const oracle_scene *s, ovec3 o, ovec3 d);                     /* raytracer.rs:29; packed 0x00RRGGBB */
+uint32_t oracle_color_mix4(uint32_t c1, uint32_t c2, uint32_t c3, uint32_t c4);             /* entities.rs:49-69 */
+uint64_t oracle_f64_as_usize(double x);                                                      /* Rust `as usize` */
+uint8_t  oracle_clamp_u8(double x);                                                          /* clamp(0,255) as u8 */
+
+/* Full frame (engine.rs:186-255 + 146-158): fb is width*height u32, row 0 top, zero-initialised by the
+ * callee (engine.rs:135).  vp = viewport {w,h,d} (engine.rs:113-119).  n_threads mimics the rayon pool
+ * (rows of each 50-row chunk handed out dynamically, barrier per chunk).  Returns 0. */
+int oracle_render(const oracle_scene *s, uint32_t width, uint32_t height, const double vp[3],
+                  uint32_t n_threads, uint32_t *fb, ocounters *counters_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,362 @@
+"""MI355X-native per-pixel hot path of conor722/rust-ray-tracer -- Python host mirror over the C ABI (include/rrt.h).
+
+The names follow the reference's host code so tests read like the reference would test itself:
+
+    SceneData  <- parse_obj_file_lines()          src/file_management/utils.rs:139, src/scene/scenedata.rs:5-13
+    Light.*                                       src/scene/entities.rs:5-9
+    RayTracer(scene_data, lights, origin)         src/scene/raytracer.rs:22-26   (.get_ray_colour -> raytracer.rs:29)
+    Scene(width, height).draw_scene(rt)           src/scene/engine.rs:177,186    (fills scene.canvas.buffer, engine.rs:127)
+
+Everything that computes goes through librrt_hip.so (hand-written HIP kernels, gfx950).  There is no CPU or
+PyTorch fallback: if the library is missing, or no GPU is visible when a RayTracer is created, this raises.
+PyTorch is only plumbing (device buffers, streams, torch.distributed) in `render_into` / `render_tiles_into`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import Iterable, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librrt_hip.so")
+
+
+class RrtError(RuntimeError):
+    def __init__(self, status: int, what: str, detail: str):
+        super().__init__(f"{what}: {detail or '?'} (status {status})")
+        self.status = status
+        self.detail = detail
+
+
+# status codes, include/rrt.h
+OK, ERR_INVALID_ARG, ERR_HIP, ERR_OOM, ERR_IO, ERR_PARSE, ERR_DEPTH, ERR_NO_DEVICE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7, -8
+
+
+class Vec3(C.Structure):
+    _fields_ = [("x", C.c_double), ("y", C.c_double), ("z", C.c_double)]
+
+
+class CLight(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("_pad", C.c_uint32), ("intensity", C.c_double), ("v", Vec3)]
+
+
+class CMaterial(C.Structure):
+    _fields_ = [("ka", Vec3), ("kd", Vec3), ("ks", Vec3), ("ns", C.c_double), ("kr", C.c_double), ("tex", C.c_int32), ("bump", C.c_int32)]
+
+
+class CTexture(C.Structure):
+    _fields_ = [("rgb", C.POINTER(C.c_uint8)), ("width", C.c_uint32), ("height", C.c_uint32)]
+
+
+class COptions(C.Structure):
+    _fields_ = [("surface_offset", C.c_double), ("max_reflection_depth", C.c_uint32), ("_pad", C.c_uint32),
+                ("vp_w", C.c_double), ("vp_h", C.c_double), ("vp_d", C.c_double)]
+
+
+class CModelInfo(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("n_tris", "n_tris_in_tree", "n_nodes", "max_depth", "n_mats", "n_tex", "root_own_count", "max_own_count")]
+
+
+class CStats(C.Structure):
+    _fields_ = [("kernel_ms", C.c_double), ("width", C.c_uint32), ("height", C.c_uint32), ("rays_primary", C.c_uint64), ("scene_bytes", C.c_uint64)]
+
+
+# every symbol include/rrt.h declares: (restype, argtypes)
+_P = C.c_void_p
+_dp, _u32p, _u8p = C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)
+SYMBOLS = {
+    "rrt_model_load_obj": (C.c_int, [C.c_char_p, _dp, C.POINTER(_P)]),
+    "rrt_model_from_arrays": (C.c_int, [C.c_uint32, _dp, _dp, _dp, _u32p, C.c_uint32, C.POINTER(CMaterial), C.c_uint32, C.POINTER(CTexture), _dp, C.POINTER(_P)]),
+    "rrt_model_destroy": (None, [_P]),
+    "rrt_model_get_info": (C.c_int, [_P, C.POINTER(CModelInfo)]),
+    "rrt_model_get_triangles": (C.c_int, [_P, _dp, _dp, _dp, _u32p]),
+    "rrt_model_get_materials": (C.c_int, [_P, C.POINTER(CMaterial)]),
+    "rrt_model_get_texture": (C.c_int, [_P, C.c_uint32, C.POINTER(CTexture)]),
+    "rrt_model_get_octree": (C.c_int, [_P, _dp, _u32p, _u32p, _u32p, _u32p]),
+    "rrt_decode_image_file": (C.c_int, [C.c_char_p, C.POINTER(_u8p), _u32p, _u32p]),
+    "rrt_free": (None, [_P]),
+    "rrt_raytracer_create": (C.c_int, [_P, C.POINTER(CLight), C.c_uint32, Vec3, C.POINTER(COptions), C.c_int, C.POINTER(_P)]),
+    "rrt_raytracer_destroy": (None, [_P]),
+    "rrt_render": (C.c_int, [_P, C.c_uint32, C.c_uint32, _u32p]),
+    "rrt_render_device": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P]),
+    "rrt_tiles_per_rank": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32]),
+    "rrt_render_tiles_device": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P]),
+    "rrt_detile_device": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P]),
+    "rrt_get_ray_colours": (C.c_int, [_P, C.c_uint32, _dp, _dp, _u32p]),
+    "rrt_intersect_rays": (C.c_int, [_P, C.c_uint32, _dp, _dp, _dp, _u8p, _dp, _dp, _dp, _u32p]),
+    "rrt_last_stats": (C.c_int, [_P, C.POINTER(CStats)]),
+    "rrt_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "rrt_strerror": (C.c_char_p, [C.c_int]),
+    "rrt_last_error_detail": (C.c_char_p, []),
+    "rrt_build_info": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load librrt_hip.so (built by __graft_entry__.build() / csrc/Makefile).  Fails loudly when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: the HIP extension was not built (run `python -c 'import __graft_entry__ as g; g.build()'`). "
+                              "There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def _check(status: int, what: str):
+    if status != OK:
+        L = lib()
+        detail = (L.rrt_last_error_detail() or b"").decode(errors="replace")
+        raise RrtError(status, f"{what} failed [{L.rrt_strerror(status).decode()}]", detail)
+
+
+def _d(a: np.ndarray):
+    return a.ctypes.data_as(_dp)
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    _check(lib().rrt_device_count(C.byref(n)), "rrt_device_count")
+    return n.value
+
+
+# ---------------------------------------------------------------------------------------------- reference-shaped host types
+@dataclass
+class Vector3d:                      # src/scene/engine.rs:9-14
+    x: float
+    y: float
+    z: float
+
+    def _c(self) -> Vec3:
+        return Vec3(float(self.x), float(self.y), float(self.z))
+
+
+@dataclass
+class Light:                         # src/scene/entities.rs:5-9
+    kind: int
+    intensity: float
+    v: Vector3d
+
+    @staticmethod
+    def Ambient(intensity: float) -> "Light":
+        return Light(0, intensity, Vector3d(0.0, 0.0, 0.0))
+
+    @staticmethod
+    def Point(intensity: float, position: Vector3d) -> "Light":
+        return Light(1, intensity, position)
+
+    @staticmethod
+    def Directional(intensity: float, direction: Vector3d) -> "Light":
+        return Light(2, intensity, direction)
+
+
+def default_lights() -> list:
+    """The lights `main` hard-codes, in its order (src/main.rs:32-58)."""
+    return [Light.Ambient(0.5), Light.Point(0.4, Vector3d(-7.0, 1.0, -15.0)), Light.Point(0.5, Vector3d(0.0, 1.0, -41.0)),
+            Light.Directional(0.4, Vector3d(-5.0, 0.0, 20.0))]
+
+
+DEFAULT_ORIGIN = Vector3d(0.0, 2.0, -10.0)   # src/main.rs:62-66
+DEFAULT_ROOT = (-20.0, 20.0, -20.0, 20.0, -20.0, 20.0)   # src/file_management/utils.rs:145
+
+
+class SceneData:
+    """SceneData (scenedata.rs:5-13): triangles in push order + materials + decoded textures + the octree."""
+
+    def __init__(self, handle: int):
+        self._h = _P(handle)
+        info = CModelInfo()
+        _check(lib().rrt_model_get_info(self._h, C.byref(info)), "rrt_model_get_info")
+        self.info = {n: getattr(info, n) for n, _ in CModelInfo._fields_}
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.rrt_model_destroy(h)
+
+    @staticmethod
+    def from_arrays(pos, uv, nrm, mat, materials: Sequence[dict], textures: Sequence[np.ndarray], root=DEFAULT_ROOT) -> "SceneData":
+        """pos/uv/nrm: [n,3,3] float64; mat: [n] uint32; materials: dicts ka,kd,ks,ns,kr,tex,bump; textures: [h,w,3] uint8."""
+        pos = np.ascontiguousarray(pos, np.float64).reshape(-1, 9)
+        uv = np.ascontiguousarray(uv, np.float64).reshape(-1, 9)
+        nrm = np.ascontiguousarray(nrm, np.float64).reshape(-1, 9)
+        mat = np.ascontiguousarray(mat, np.uint32)
+        n = pos.shape[0]
+        cm = (CMaterial * max(1, len(materials)))()
+        for i, m in enumerate(materials):
+            cm[i] = CMaterial(Vec3(*m["ka"]), Vec3(*m["kd"]), Vec3(*m["ks"]), float(m["ns"]), float(m["kr"]), int(m["tex"]), int(m.get("bump", -1)))
+        keep = [np.ascontiguousarray(t, np.uint8) for t in textures]
+        ct = (CTexture * max(1, len(keep)))()
+        for i, t in enumerate(keep):
+            ct[i] = CTexture(t.ctypes.data_as(_u8p), t.shape[1], t.shape[0])
+        r = (C.c_double * 6)(*root)
+        out = _P()
+        _check(lib().rrt_model_from_arrays(n, _d(pos), _d(uv), _d(nrm), mat.ctypes.data_as(_u32p), len(materials), cm, len(keep), ct, r, C.byref(out)),
+               "rrt_model_from_arrays")
+        return SceneData(out.value)
+
+    # --- accessors
+    def triangles(self):
+        n = self.info["n_tris"]
+        pos, uv, nrm, mat = (np.empty((n, 3, 3)), np.empty((n, 3, 3)), np.empty((n, 3, 3)), np.empty(n, np.uint32))
+        _check(lib().rrt_model_get_triangles(self._h, _d(pos), _d(uv), _d(nrm), mat.ctypes.data_as(_u32p)), "rrt_model_get_triangles")
+        return pos, uv, nrm, mat
+
+    def materials(self) -> list:
+        n = self.info["n_mats"]
+        cm = (CMaterial * max(1, n))()
+        _check(lib().rrt_model_get_materials(self._h, cm), "rrt_model_get_materials")
+        v = lambda a: (a.x, a.y, a.z)
+        return [dict(ka=v(m.ka), kd=v(m.kd), ks=v(m.ks), ns=m.ns, kr=m.kr, tex=m.tex, bump=m.bump) for m in cm[:n]]
+
+    def texture(self, i: int) -> np.ndarray:
+        t = CTexture()
+        _check(lib().rrt_model_get_texture(self._h, i, C.byref(t)), "rrt_model_get_texture")
+        return np.ctypeslib.as_array(t.rgb, shape=(t.height, t.width, 3)).copy()
+
+    def textures(self) -> list:
+        return [self.texture(i) for i in range(self.info["n_tex"])]
+
+    def octree(self) -> dict:
+        n = self.info["n_nodes"]
+        aabb = np.empty((n, 6)); fc = np.empty(n, np.uint32); tc = np.empty(n, np.uint32); off = np.empty(n + 1, np.uint32)
+        idx = np.empty(self.info["n_tris_in_tree"], np.uint32)
+        u = lambda a: a.ctypes.data_as(_u32p)
+        _check(lib().rrt_model_get_octree(self._h, _d(aabb), u(fc), u(tc), u(off), u(idx)), "rrt_model_get_octree")
+        return dict(aabb=aabb, first_child=fc, tri_count=tc, own_off=off, own_idx=idx, max_depth=self.info["max_depth"])
+
+
+def parse_obj_file(path: str, root=DEFAULT_ROOT) -> SceneData:
+    """fs::read_to_string + parse_obj_file_lines (src/main.rs:28-30, src/file_management/utils.rs:139-213)."""
+    r = (C.c_double * 6)(*root)
+    out = _P()
+    _check(lib().rrt_model_load_obj(os.fsencode(path), r, C.byref(out)), f"parse_obj_file({path})")
+    return SceneData(out.value)
+
+
+def decode_image_file(path: str) -> np.ndarray:
+    """The build-owned stand-in for `image::ImageReader::open(..).decode()` (utils.rs:345-350): [h,w,3] uint8."""
+    p = _u8p(); w = C.c_uint32(); h = C.c_uint32()
+    _check(lib().rrt_decode_image_file(os.fsencode(path), C.byref(p), C.byref(w), C.byref(h)), f"decode_image_file({path})")
+    try:
+        return np.ctypeslib.as_array(p, shape=(h.value, w.value, 3)).copy()
+    finally:
+        lib().rrt_free(p)
+
+
+class RayTracer:
+    """RayTracer{scene_data, lights, origin} (raytracer.rs:22-26), uploaded once to one MI355X."""
+
+    def __init__(self, scene_data: SceneData, lights: Iterable[Light], origin: Vector3d = DEFAULT_ORIGIN, device: int = 0,
+                 surface_offset: float = 0.0001, max_reflection_depth: int = 5, viewport=(1.0, 1.0, 1.0)):
+        self.scene_data, self.lights, self.origin, self.device = scene_data, list(lights), origin, device
+        cl = (CLight * max(1, len(self.lights)))()
+        for i, l in enumerate(self.lights):
+            cl[i] = CLight(l.kind, 0, float(l.intensity), l.v._c())
+        opt = COptions(surface_offset, max_reflection_depth, 0, *map(float, viewport))
+        out = _P()
+        _check(lib().rrt_raytracer_create(scene_data._h, cl, len(self.lights), origin._c(), C.byref(opt), device, C.byref(out)), "rrt_raytracer_create")
+        self._h = out
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.rrt_raytracer_destroy(h)
+
+    # raytracer.rs:29, batched
+    def get_ray_colours(self, origins, dirs) -> np.ndarray:
+        o = np.ascontiguousarray(origins, np.float64).reshape(-1, 3); d = np.ascontiguousarray(dirs, np.float64).reshape(-1, 3)
+        assert o.shape == d.shape
+        out = np.empty(o.shape[0], np.uint32)
+        _check(lib().rrt_get_ray_colours(self._h, o.shape[0], _d(o), _d(d), out.ctypes.data_as(_u32p)), "rrt_get_ray_colours")
+        return out
+
+    def get_ray_colour(self, origin: Vector3d, direction: Vector3d) -> int:
+        return int(self.get_ray_colours([[origin.x, origin.y, origin.z]], [[direction.x, direction.y, direction.z]])[0])
+
+    # ray.rs:96-168, batched
+    def intersect_rays(self, origins, dirs, max_t=None):
+        o = np.ascontiguousarray(origins, np.float64).reshape(-1, 3); d = np.ascontiguousarray(dirs, np.float64).reshape(-1, 3)
+        n = o.shape[0]
+        mt = None if max_t is None else np.ascontiguousarray(np.broadcast_to(np.asarray(max_t, np.float64), (n,)))
+        hit = np.empty(n, np.uint8); t = np.empty(n); u = np.empty(n); v = np.empty(n); tri = np.empty(n, np.uint32)
+        _check(lib().rrt_intersect_rays(self._h, n, _d(o), _d(d), None if mt is None else _d(mt), hit.ctypes.data_as(_u8p), _d(t), _d(u), _d(v),
+                                        tri.ctypes.data_as(_u32p)), "rrt_intersect_rays")
+        return hit.astype(bool), t, u, v, tri
+
+    # engine.rs:186 via the C ABI, host framebuffer
+    def render(self, width: int, height: int) -> np.ndarray:
+        fb = np.empty((height, width), np.uint32)
+        _check(lib().rrt_render(self._h, width, height, fb.ctypes.data_as(_u32p)), "rrt_render")
+        return fb
+
+    # device-resident variants (torch tensors are plumbing: data_ptr + current stream)
+    def render_into(self, fb_tensor, width: int, height: int, stream: Optional[int] = None):
+        assert fb_tensor.is_cuda and fb_tensor.is_contiguous() and fb_tensor.numel() == width * height and fb_tensor.element_size() == 4
+        _check(lib().rrt_render_device(self._h, width, height, _P(fb_tensor.data_ptr()), _P(_stream(stream))), "rrt_render_device")
+
+    def render_tiles_into(self, tiles_tensor, width: int, height: int, rank: int, world: int, stream: Optional[int] = None):
+        need = tiles_per_rank(width, height, world) * 64
+        assert tiles_tensor.is_cuda and tiles_tensor.is_contiguous() and tiles_tensor.numel() == need and tiles_tensor.element_size() == 4
+        _check(lib().rrt_render_tiles_device(self._h, width, height, rank, world, _P(tiles_tensor.data_ptr()), _P(_stream(stream))), "rrt_render_tiles_device")
+
+    def detile_into(self, gathered_tensor, fb_tensor, width: int, height: int, world: int, stream: Optional[int] = None):
+        assert gathered_tensor.numel() == tiles_per_rank(width, height, world) * 64 * world and fb_tensor.numel() == width * height
+        _check(lib().rrt_detile_device(self._h, width, height, world, _P(gathered_tensor.data_ptr()), _P(fb_tensor.data_ptr()), _P(_stream(stream))),
+               "rrt_detile_device")
+
+    def last_stats(self) -> dict:
+        s = CStats()
+        _check(lib().rrt_last_stats(self._h, C.byref(s)), "rrt_last_stats")
+        return {n: getattr(s, n) for n, _ in CStats._fields_}
+
+
+def _stream(stream: Optional[int]) -> int:
+    if stream is not None:
+        return stream
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def tiles_per_rank(width: int, height: int, world: int) -> int:
+    return int(lib().rrt_tiles_per_rank(width, height, world))
+
+
+def tile_owner_map(width: int, height: int, world: int) -> np.ndarray:
+    """[tiles_y, tiles_x] rank owning each 8x8-pixel tile (tile k -> k % world) -- host mirror of the kernel's partition."""
+    tx, ty = (width + 7) // 8, (height + 7) // 8
+    return (np.arange(tx * ty, dtype=np.int64) % world).reshape(ty, tx)
+
+
+def detile_host(gathered: np.ndarray, width: int, height: int, world: int) -> np.ndarray:
+    """Host mirror of rrt_detile_device (used by the gloo tests): gathered[world, tiles_per_rank, 64] -> fb[height, width]."""
+    tx, ty = (width + 7) // 8, (height + 7) // 8
+    tpr = (tx * ty + world - 1) // world
+    g = np.asarray(gathered, np.uint32).reshape(world, tpr, 8, 8)
+    k = np.arange(tx * ty)
+    tiles = g[k % world, k // world].reshape(ty, tx, 8, 8)
+    return tiles.transpose(0, 2, 1, 3).reshape(ty * 8, tx * 8)[:height, :width].copy()
+
+
+class Canvas:                        # src/scene/engine.rs:123-167 minus the minifb window
+    def __init__(self, width: int, height: int):
+        self.width, self.height = width, height
+        self.buffer = np.zeros((height, width), np.uint32)   # engine.rs:135
+
+
+class Scene:                         # src/scene/engine.rs:171-256
+    def __init__(self, width: int, height: int):
+        self.canvas = Canvas(width, height)
+
+    def draw_scene(self, rt: RayTracer) -> None:
+        """Scene::draw_scene (engine.rs:186): one HIP launch instead of the rayon row loop; fills canvas.buffer."""
+        self.canvas.buffer = rt.render(self.canvas.width, self.canvas.height)

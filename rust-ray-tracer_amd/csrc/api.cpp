@@ -1,0 +1,470 @@
+// api.cpp -- the extern "C" surface declared in include/rrt.h: scene upload (once, to HBM) and kernel launches.
+// No CPU rendering path exists in this library; every compute entry point launches the HIP kernels of render.hip.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <new>
+
+#include "device_scene.hpp"
+#include "model.hpp"
+
+struct rrt_model { rrt::Model m; };
+
+struct rrt_raytracer {
+    int device = 0;
+    rrt::DevScene scene{};
+    rrt_options opt{};
+    std::vector<void*> allocs;       // every hipMalloc of this raytracer
+    uint64_t scene_bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    rrt_stats stats{};
+    bool stats_pending = false;
+};
+
+namespace rrt {
+namespace {
+thread_local std::string g_detail;
+}
+void set_error_detail(const std::string& s) { g_detail = s; }
+}  // namespace rrt
+
+namespace {
+
+using namespace rrt;
+
+struct HipFail { hipError_t e; const char* what; };
+#define HIP_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) throw HipFail{_e, #expr}; } while (0)
+
+template <class F> int guarded(F&& f) {
+    try { return f(); }
+    catch (const Error& e) { set_error_detail(e.detail); return e.status; }
+    catch (const HipFail& h) {
+        set_error_detail(std::string(h.what) + ": " + hipGetErrorString(h.e));
+        (void)hipGetLastError();
+        return (h.e == hipErrorOutOfMemory) ? RRT_ERR_OOM : (h.e == hipErrorNoDevice || h.e == hipErrorInvalidDevice) ? RRT_ERR_NO_DEVICE : RRT_ERR_HIP;
+    }
+    catch (const std::bad_alloc&) { set_error_detail("host allocation failed"); return RRT_ERR_OOM; }
+    catch (const std::exception& e) { set_error_detail(e.what()); return RRT_ERR_INVALID_ARG; }
+    catch (...) { set_error_detail("unknown failure"); return RRT_ERR_INVALID_ARG; }
+}
+
+Box default_root(const double* root) {
+    Box b;
+    if (root) { b.lo[0] = root[0]; b.hi[0] = root[1]; b.lo[1] = root[2]; b.hi[1] = root[3]; b.lo[2] = root[4]; b.hi[2] = root[5]; }
+    else for (int k = 0; k < 3; k++) { b.lo[k] = -20.0; b.hi[k] = 20.0; }   // utils.rs:145
+    return b;
+}
+
+void validate_model(const Model& m) {
+    if (m.tree.max_depth > RRT_MAX_OCTREE_DEPTH) throw Error{RRT_ERR_DEPTH, "octree depth " + std::to_string(m.tree.max_depth) + " exceeds RRT_MAX_OCTREE_DEPTH"};
+    for (auto& t : m.textures) if (t.width == 0 || t.height == 0 || t.rgb.size() != (size_t)3 * t.width * t.height) throw Error{RRT_ERR_INVALID_ARG, "texture with bad dimensions"};
+    for (auto& mat : m.materials) {
+        if (mat.tex < 0 || (size_t)mat.tex >= m.textures.size()) throw Error{RRT_ERR_INVALID_ARG, "material texture index out of range"};
+        if (mat.bump >= (int32_t)m.textures.size()) throw Error{RRT_ERR_INVALID_ARG, "material bump index out of range"};
+    }
+    for (auto& t : m.triangles) if (t.mat >= m.materials.size()) throw Error{RRT_ERR_INVALID_ARG, "triangle material index out of range"};
+}
+
+template <class T> T* upload(rrt_raytracer* rt, const T* host, size_t count) {
+    void* d = nullptr;
+    const size_t bytes = sizeof(T) * (count ? count : 1);
+    HIP_TRY(hipMalloc(&d, bytes));
+    rt->allocs.push_back(d);
+    if (count) HIP_TRY(hipMemcpy(d, host, sizeof(T) * count, hipMemcpyHostToDevice));
+    rt->scene_bytes += sizeof(T) * count;
+    return static_cast<T*>(d);
+}
+
+struct DeviceGuard {
+    int prev = 0;
+    explicit DeviceGuard(int dev) { HIP_TRY(hipGetDevice(&prev)); if (prev != dev) HIP_TRY(hipSetDevice(dev)); cur = dev; }
+    ~DeviceGuard() { if (prev != cur) (void)hipSetDevice(prev); }
+    int cur = 0;
+};
+
+FrameParams frame_params(const rrt_raytracer* rt, uint32_t width, uint32_t height, uint32_t rank, uint32_t world, bool tiled) {
+    FrameParams f{};
+    f.width = width; f.height = height;
+    f.x_scale = rt->opt.vp_w / (double)width;      // engine.rs:189
+    f.y_scale = rt->opt.vp_h / (double)height;     // engine.rs:190
+    f.z_value = rt->opt.vp_d;                      // engine.rs:191
+    f.tiles_x = (width + 7) / 8; f.tiles_y = (height + 7) / 8;
+    f.rank = rank; f.world = world; f.tiled_output = tiled ? 1u : 0u;
+    return f;
+}
+
+void check_frame(const rrt_raytracer* rt, uint32_t width, uint32_t height) {
+    if (!rt) throw Error{RRT_ERR_INVALID_ARG, "null raytracer"};
+    if (width == 0 || height == 0 || (uint64_t)width * height > 0x7FFFFFFFull) throw Error{RRT_ERR_INVALID_ARG, "bad frame size"};
+}
+
+void record_launch(rrt_raytracer* rt, uint32_t width, uint32_t height, uint32_t rank, uint32_t world) {
+    rt->stats.width = width; rt->stats.height = height;
+    const uint64_t wt = 2ull * (width / 2), ht = height >= 2 ? (uint64_t)(2 * (height / 2) - 1) : 0;   // traced pixels: see render_kernel
+    rt->stats.rays_primary = world == 1 ? 4ull * wt * ht : 0;   // per-rank share is not tracked
+    (void)rank;
+    rt->stats.scene_bytes = rt->scene_bytes;
+    rt->stats_pending = true;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rrt_strerror(int status) {
+    switch (status) {
+        case RRT_OK: return "ok";
+        case RRT_ERR_INVALID_ARG: return "invalid argument";
+        case RRT_ERR_HIP: return "HIP runtime error";
+        case RRT_ERR_OOM: return "out of memory";
+        case RRT_ERR_IO: return "could not read file";
+        case RRT_ERR_PARSE: return "parse error";
+        case RRT_ERR_DEPTH: return "octree too deep";
+        case RRT_ERR_NO_DEVICE: return "no usable HIP device";
+        case RRT_ERR_UNSUPPORTED: return "unsupported input";
+        default: return "unknown status";
+    }
+}
+const char* rrt_last_error_detail(void) { return rrt::g_detail.c_str(); }
+const char* rrt_build_info(void) { return "librrt_hip: offload-arch=gfx950, f64, -ffp-contract=off, wave64 node-coherent octree walk"; }
+void rrt_free(void* p) { std::free(p); }
+
+int rrt_device_count(int* count) {
+    return guarded([&]() -> int {
+        if (!count) throw Error{RRT_ERR_INVALID_ARG, "null count"};
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess) { (void)hipGetLastError(); n = 0; }
+        *count = n;
+        return RRT_OK;
+    });
+}
+
+int rrt_model_load_obj(const char* obj_path, const double* root, rrt_model** out) {
+    return guarded([&]() -> int {
+        if (!obj_path || !out) throw Error{RRT_ERR_INVALID_ARG, "null argument"};
+        auto m = std::make_unique<rrt_model>();
+        load_obj(obj_path, default_root(root), m->m);
+        validate_model(m->m);
+        *out = m.release();
+        return RRT_OK;
+    });
+}
+
+int rrt_model_from_arrays(uint32_t n_tris, const double* pos, const double* uv, const double* nrm, const uint32_t* mat,
+                          uint32_t n_mats, const rrt_material* mats, uint32_t n_tex, const rrt_texture* tex,
+                          const double* root, rrt_model** out) {
+    return guarded([&]() -> int {
+        if (!out || (n_tris && (!pos || !uv || !nrm || !mat)) || (n_mats && !mats) || (n_tex && !tex)) throw Error{RRT_ERR_INVALID_ARG, "null argument"};
+        auto m = std::make_unique<rrt_model>();
+        Model& M = m->m;
+        M.root = default_root(root);
+        M.materials.assign(mats, mats + n_mats);
+        M.textures.resize(n_tex);
+        for (uint32_t i = 0; i < n_tex; i++) {
+            if (!tex[i].rgb) throw Error{RRT_ERR_INVALID_ARG, "null texture data"};
+            M.textures[i].width = tex[i].width; M.textures[i].height = tex[i].height;
+            M.textures[i].rgb.assign(tex[i].rgb, tex[i].rgb + (size_t)3 * tex[i].width * tex[i].height);
+        }
+        M.triangles.resize(n_tris);
+        auto rd = [](const double* p) { Vec3 v; v.x = p[0]; v.y = p[1]; v.z = p[2]; return v; };
+        for (uint32_t i = 0; i < n_tris; i++) {
+            Triangle& t = M.triangles[i];
+            t.v1 = rd(pos + 9 * (size_t)i); t.v2 = rd(pos + 9 * (size_t)i + 3); t.v3 = rd(pos + 9 * (size_t)i + 6);
+            t.t1 = rd(uv + 9 * (size_t)i);  t.t2 = rd(uv + 9 * (size_t)i + 3);  t.t3 = rd(uv + 9 * (size_t)i + 6);
+            t.n1 = rd(nrm + 9 * (size_t)i); t.n2 = rd(nrm + 9 * (size_t)i + 3); t.n3 = rd(nrm + 9 * (size_t)i + 6);
+            t.mat = mat[i];
+        }
+        build_octree(M.triangles, M.root, M.tree);
+        validate_model(M);
+        *out = m.release();
+        return RRT_OK;
+    });
+}
+
+void rrt_model_destroy(rrt_model* m) { delete m; }
+
+int rrt_model_get_info(const rrt_model* m, rrt_model_info* out) {
+    return guarded([&]() -> int {
+        if (!m || !out) throw Error{RRT_ERR_INVALID_ARG, "null argument"};
+        const FlatOctree& T = m->m.tree;
+        std::memset(out, 0, sizeof *out);
+        out->n_tris = (uint32_t)m->m.triangles.size();
+        out->n_tris_in_tree = (uint32_t)T.own_idx.size();
+        out->n_nodes = (uint32_t)T.box.size(); out->max_depth = T.max_depth;
+        out->n_mats = (uint32_t)m->m.materials.size(); out->n_tex = (uint32_t)m->m.textures.size();
+        out->root_own_count = T.own_off[1] - T.own_off[0];
+        for (size_t i = 0; i + 1 < T.own_off.size(); i++) out->max_own_count = std::max(out->max_own_count, T.own_off[i + 1] - T.own_off[i]);
+        return RRT_OK;
+    });
+}
+
+int rrt_model_get_triangles(const rrt_model* m, double* pos, double* uv, double* nrm, uint32_t* mat) {
+    return guarded([&]() -> int {
+        if (!m) throw Error{RRT_ERR_INVALID_ARG, "null model"};
+        auto wr = [](double* p, const Vec3& v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; };
+        for (size_t i = 0; i < m->m.triangles.size(); i++) {
+            const Triangle& t = m->m.triangles[i];
+            if (pos) { wr(pos + 9 * i, t.v1); wr(pos + 9 * i + 3, t.v2); wr(pos + 9 * i + 6, t.v3); }
+            if (uv)  { wr(uv + 9 * i, t.t1);  wr(uv + 9 * i + 3, t.t2);  wr(uv + 9 * i + 6, t.t3); }
+            if (nrm) { wr(nrm + 9 * i, t.n1); wr(nrm + 9 * i + 3, t.n2); wr(nrm + 9 * i + 6, t.n3); }
+            if (mat) mat[i] = t.mat;
+        }
+        return RRT_OK;
+    });
+}
+
+int rrt_model_get_materials(const rrt_model* m, rrt_material* out) {
+    return guarded([&]() -> int {
+        if (!m || !out) throw Error{RRT_ERR_INVALID_ARG, "null argument"};
+        std::copy(m->m.materials.begin(), m->m.materials.end(), out);
+        return RRT_OK;
+    });
+}
+
+int rrt_model_get_texture(const rrt_model* m, uint32_t index, rrt_texture* out) {
+    return guarded([&]() -> int {
+        if (!m || !out || index >= m->m.textures.size()) throw Error{RRT_ERR_INVALID_ARG, "bad texture index"};
+        const Texture& t = m->m.textures[index];
+        out->rgb = t.rgb.data(); out->width = t.width; out->height = t.height;
+        return RRT_OK;
+    });
+}
+
+int rrt_model_get_octree(const rrt_model* m, double* aabb, uint32_t* first_child, uint32_t* tri_count, uint32_t* own_off, uint32_t* own_idx) {
+    return guarded([&]() -> int {
+        if (!m) throw Error{RRT_ERR_INVALID_ARG, "null model"};
+        const FlatOctree& T = m->m.tree;
+        const size_t n = T.box.size();
+        if (aabb) for (size_t i = 0; i < n; i++) for (int k = 0; k < 3; k++) { aabb[6 * i + k] = T.box[i].lo[k]; aabb[6 * i + 3 + k] = T.box[i].hi[k]; }
+        if (first_child) std::copy(T.first_child.begin(), T.first_child.end(), first_child);
+        if (tri_count) std::copy(T.tri_count.begin(), T.tri_count.end(), tri_count);
+        if (own_off) std::copy(T.own_off.begin(), T.own_off.end(), own_off);
+        if (own_idx) std::copy(T.own_idx.begin(), T.own_idx.end(), own_idx);
+        return RRT_OK;
+    });
+}
+
+int rrt_decode_image_file(const char* path, uint8_t** rgb, uint32_t* width, uint32_t* height) {
+    return guarded([&]() -> int {
+        if (!path || !rgb || !width || !height) throw Error{RRT_ERR_INVALID_ARG, "null argument"};
+        std::vector<uint8_t> bytes; uint32_t w = 0, h = 0, ch = 0;
+        decode_image_file(path, bytes, w, h, ch);
+        if (ch != 3) throw Error{RRT_ERR_UNSUPPORTED, "image is not 3 bytes per pixel"};
+        uint8_t* p = static_cast<uint8_t*>(std::malloc(bytes.size() ? bytes.size() : 1));
+        if (!p) throw std::bad_alloc();
+        std::memcpy(p, bytes.data(), bytes.size());
+        *rgb = p; *width = w; *height = h;
+        return RRT_OK;
+    });
+}
+
+// ------------------------------------------------------------------------------------------------ raytracer
+int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n_lights, rrt_vec3 origin,
+                         const rrt_options* opt, int device, rrt_raytracer** out) {
+    return guarded([&]() -> int {
+        if (!m || !out || (n_lights && !lights)) throw Error{RRT_ERR_INVALID_ARG, "null argument"};
+        if (n_lights > RRT_MAX_LIGHTS) throw Error{RRT_ERR_INVALID_ARG, "too many lights (max 16)"};
+        for (uint32_t i = 0; i < n_lights; i++) if (lights[i].kind > 2) throw Error{RRT_ERR_INVALID_ARG, "bad light kind"};
+        rrt_options o;
+        if (opt) o = *opt; else { o.surface_offset = 0.0001; o.max_reflection_depth = 5; o._pad = 0; o.vp_w = o.vp_h = o.vp_d = 1.0; }
+        if (o.max_reflection_depth > RRT_MAX_REFLECT) throw Error{RRT_ERR_INVALID_ARG, "max_reflection_depth > 8"};
+        int n_dev = 0;
+        if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) { (void)hipGetLastError(); throw Error{RRT_ERR_NO_DEVICE, "no HIP device visible"}; }
+        if (device < 0 || device >= n_dev) throw Error{RRT_ERR_NO_DEVICE, "device index out of range"};
+        DeviceGuard guard(device);
+
+        std::unique_ptr<rrt_raytracer, void (*)(rrt_raytracer*)> rt(new rrt_raytracer, rrt_raytracer_destroy);
+        rt->device = device; rt->opt = o;
+        const Model& M = m->m; const FlatOctree& T = M.tree;
+        const size_t n_nodes = T.box.size(), n_slots = T.own_idx.size();
+
+        std::vector<DevNode> nodes(n_nodes);
+        for (size_t i = 0; i < n_nodes; i++) {
+            DevNode& d = nodes[i];
+            for (int k = 0; k < 3; k++) { d.lo[k] = T.box[i].lo[k]; d.hi[k] = T.box[i].hi[k]; }
+            d.first_child = T.first_child[i]; d.own_begin = T.own_off[i]; d.own_count = T.own_off[i + 1] - T.own_off[i];
+            d.flags = T.tri_count[i] ? 0x100u : 0u;
+            if (d.first_child) for (uint32_t k = 0; k < 8; k++) if (T.tri_count[d.first_child + k]) d.flags |= 1u << k;
+        }
+        std::vector<DevTriGeom> geom(n_slots); std::vector<DevTriAttr> attr(n_slots);
+        for (size_t s = 0; s < n_slots; s++) {
+            const Triangle& t = M.triangles[T.own_idx[s]];
+            DevTriGeom& g = geom[s];
+            g.v1[0] = t.v1.x; g.v1[1] = t.v1.y; g.v1[2] = t.v1.z;
+            g.e1[0] = t.v2.x - t.v1.x; g.e1[1] = t.v2.y - t.v1.y; g.e1[2] = t.v2.z - t.v1.z;   // ray.rs:60
+            g.e2[0] = t.v3.x - t.v1.x; g.e2[1] = t.v3.y - t.v1.y; g.e2[2] = t.v3.z - t.v1.z;   // ray.rs:61
+            DevTriAttr& a = attr[s];
+            a.uv[0] = t.t1.x; a.uv[1] = t.t1.y; a.uv[2] = t.t2.x; a.uv[3] = t.t2.y; a.uv[4] = t.t3.x; a.uv[5] = t.t3.y;
+            a.nrm[0] = t.n1.x; a.nrm[1] = t.n1.y; a.nrm[2] = t.n1.z; a.nrm[3] = t.n2.x; a.nrm[4] = t.n2.y; a.nrm[5] = t.n2.z;
+            a.nrm[6] = t.n3.x; a.nrm[7] = t.n3.y; a.nrm[8] = t.n3.z;
+            a.mat = t.mat; a.orig = T.own_idx[s];
+        }
+        std::vector<DevMaterial> mats(M.materials.size());
+        for (size_t i = 0; i < mats.size(); i++) {
+            const rrt_material& s = M.materials[i]; DevMaterial& d = mats[i];
+            d.ka[0] = s.ka.x; d.ka[1] = s.ka.y; d.ka[2] = s.ka.z; d.kd[0] = s.kd.x; d.kd[1] = s.kd.y; d.kd[2] = s.kd.z;
+            d.ks[0] = s.ks.x; d.ks[1] = s.ks.y; d.ks[2] = s.ks.z; d.ns = s.ns; d.kr = s.kr; d.tex = s.tex; d.bump = s.bump;
+        }
+        std::vector<DevTexture> texs(M.textures.size());
+        for (size_t i = 0; i < texs.size(); i++) {
+            texs[i].rgb = upload(rt.get(), M.textures[i].rgb.data(), M.textures[i].rgb.size());
+            texs[i].width = M.textures[i].width; texs[i].height = M.textures[i].height;
+        }
+        DevScene& S = rt->scene;
+        S.nodes = upload(rt.get(), nodes.data(), nodes.size());
+        S.geom = upload(rt.get(), geom.data(), geom.size());
+        S.attr = upload(rt.get(), attr.data(), attr.size());
+        S.mats = upload(rt.get(), mats.data(), mats.size());
+        S.tex = upload(rt.get(), texs.data(), texs.size());
+        S.n_nodes = (uint32_t)n_nodes; S.n_slots = (uint32_t)n_slots; S.n_mats = (uint32_t)mats.size(); S.n_tex = (uint32_t)texs.size();
+        S.n_lights = n_lights; S.max_reflection_depth = o.max_reflection_depth; S.stack_levels = T.max_depth; S._pad = 0;
+        S.origin[0] = origin.x; S.origin[1] = origin.y; S.origin[2] = origin.z;
+        S.surface_offset = o.surface_offset;
+        for (uint32_t i = 0; i < n_lights; i++) {
+            S.lights[i].kind = lights[i].kind; S.lights[i]._pad = 0; S.lights[i].intensity = lights[i].intensity;
+            S.lights[i].v[0] = lights[i].v.x; S.lights[i].v[1] = lights[i].v.y; S.lights[i].v[2] = lights[i].v.z;
+        }
+        HIP_TRY(hipEventCreate(&rt->ev0)); HIP_TRY(hipEventCreate(&rt->ev1));
+        HIP_TRY(hipDeviceSynchronize());
+        *out = rt.release();
+        return RRT_OK;
+    });
+}
+
+void rrt_raytracer_destroy(rrt_raytracer* rt) {
+    if (!rt) return;
+    int prev = 0;
+    if (hipGetDevice(&prev) == hipSuccess) {
+        (void)hipSetDevice(rt->device);
+        for (void* p : rt->allocs) (void)hipFree(p);
+        if (rt->ev0) (void)hipEventDestroy(rt->ev0);
+        if (rt->ev1) (void)hipEventDestroy(rt->ev1);
+        (void)hipSetDevice(prev);
+    }
+    delete rt;
+}
+
+uint32_t rrt_tiles_per_rank(uint32_t width, uint32_t height, uint32_t world) {
+    if (world == 0) return 0;
+    const uint32_t n = ((width + 7) / 8) * ((height + 7) / 8);
+    return (n + world - 1) / world;
+}
+
+int rrt_render_tiles_device(rrt_raytracer* rt, uint32_t width, uint32_t height, uint32_t rank, uint32_t world, void* d_tiles, void* stream) {
+    return guarded([&]() -> int {
+        check_frame(rt, width, height);
+        if (!d_tiles || world == 0 || rank >= world) throw Error{RRT_ERR_INVALID_ARG, "bad rank/world/buffer"};
+        DeviceGuard guard(rt->device);
+        const FrameParams f = frame_params(rt, width, height, rank, world, true);
+        HIP_TRY(hipEventRecord(rt->ev0, (hipStream_t)stream));
+        HIP_TRY((hipError_t)launch_render(rt->scene, f, static_cast<uint32_t*>(d_tiles), stream));
+        HIP_TRY(hipEventRecord(rt->ev1, (hipStream_t)stream));
+        record_launch(rt, width, height, rank, world);
+        return RRT_OK;
+    });
+}
+
+int rrt_render_device(rrt_raytracer* rt, uint32_t width, uint32_t height, void* d_fb, void* stream) {
+    return guarded([&]() -> int {
+        check_frame(rt, width, height);
+        if (!d_fb) throw Error{RRT_ERR_INVALID_ARG, "null framebuffer"};
+        DeviceGuard guard(rt->device);
+        const FrameParams f = frame_params(rt, width, height, 0, 1, false);
+        HIP_TRY(hipEventRecord(rt->ev0, (hipStream_t)stream));
+        HIP_TRY((hipError_t)launch_render(rt->scene, f, static_cast<uint32_t*>(d_fb), stream));
+        HIP_TRY(hipEventRecord(rt->ev1, (hipStream_t)stream));
+        record_launch(rt, width, height, 0, 1);
+        return RRT_OK;
+    });
+}
+
+int rrt_detile_device(rrt_raytracer* rt, uint32_t width, uint32_t height, uint32_t world, const void* d_gathered, void* d_fb, void* stream) {
+    return guarded([&]() -> int {
+        check_frame(rt, width, height);
+        if (!d_gathered || !d_fb || world == 0) throw Error{RRT_ERR_INVALID_ARG, "bad argument"};
+        DeviceGuard guard(rt->device);
+        HIP_TRY((hipError_t)launch_detile(width, height, world, static_cast<const uint32_t*>(d_gathered), static_cast<uint32_t*>(d_fb), stream));
+        return RRT_OK;
+    });
+}
+
+int rrt_render(rrt_raytracer* rt, uint32_t width, uint32_t height, uint32_t* out_fb) {
+    return guarded([&]() -> int {
+        check_frame(rt, width, height);
+        if (!out_fb) throw Error{RRT_ERR_INVALID_ARG, "null framebuffer"};
+        DeviceGuard guard(rt->device);
+        const size_t bytes = sizeof(uint32_t) * (size_t)width * height;
+        void* d = nullptr;
+        HIP_TRY(hipMalloc(&d, bytes));
+        int rc = rrt_render_device(rt, width, height, d, nullptr);
+        hipError_t e = rc == RRT_OK ? hipMemcpy(out_fb, d, bytes, hipMemcpyDeviceToHost) : hipSuccess;
+        (void)hipFree(d);
+        if (rc != RRT_OK) return rc;
+        HIP_TRY(e);
+        return RRT_OK;
+    });
+}
+
+int rrt_get_ray_colours(rrt_raytracer* rt, uint32_t n, const double* origins, const double* dirs, uint32_t* colours) {
+    return guarded([&]() -> int {
+        if (!rt || (n && (!origins || !dirs || !colours))) throw Error{RRT_ERR_INVALID_ARG, "null argument"};
+        if (n == 0) return (int)RRT_OK;
+        DeviceGuard guard(rt->device);
+        double *d_o = nullptr, *d_d = nullptr; uint32_t* d_c = nullptr;
+        struct Cleanup { void** p[3]; ~Cleanup() { for (auto q : p) if (*q) (void)hipFree(*q); } } cl{{(void**)&d_o, (void**)&d_d, (void**)&d_c}};
+        HIP_TRY(hipMalloc((void**)&d_o, sizeof(double) * 3 * (size_t)n)); HIP_TRY(hipMalloc((void**)&d_d, sizeof(double) * 3 * (size_t)n)); HIP_TRY(hipMalloc((void**)&d_c, sizeof(uint32_t) * (size_t)n));
+        HIP_TRY(hipMemcpy(d_o, origins, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_d, dirs, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice));
+        HIP_TRY((hipError_t)launch_ray_colours(rt->scene, n, d_o, d_d, d_c, nullptr));
+        HIP_TRY(hipMemcpy(colours, d_c, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost));
+        return (int)RRT_OK;
+    });
+}
+
+int rrt_intersect_rays(rrt_raytracer* rt, uint32_t n, const double* origins, const double* dirs, const double* max_t,
+                       uint8_t* hit, double* t, double* u, double* v, uint32_t* tri) {
+    return guarded([&]() -> int {
+        if (!rt || (n && (!origins || !dirs || !hit || !t || !u || !v || !tri))) throw Error{RRT_ERR_INVALID_ARG, "null argument"};
+        if (n == 0) return (int)RRT_OK;
+        DeviceGuard guard(rt->device);
+        void* bufs[9] = {};
+        struct Cleanup { void** b; ~Cleanup() { for (int i = 0; i < 9; i++) if (b[i]) (void)hipFree(b[i]); } } cl{bufs};
+        const size_t N = n;
+        const size_t sizes[9] = {24 * N, 24 * N, 8 * N, N, 8 * N, 8 * N, 8 * N, 4 * N, 0};
+        for (int i = 0; i < 8; i++) HIP_TRY(hipMalloc(&bufs[i], sizes[i]));
+        HIP_TRY(hipMemcpy(bufs[0], origins, 24 * N, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(bufs[1], dirs, 24 * N, hipMemcpyHostToDevice));
+        if (max_t) HIP_TRY(hipMemcpy(bufs[2], max_t, 8 * N, hipMemcpyHostToDevice));
+        HIP_TRY((hipError_t)launch_intersect(rt->scene, n, (const double*)bufs[0], (const double*)bufs[1], max_t ? (const double*)bufs[2] : nullptr,
+                                             (uint8_t*)bufs[3], (double*)bufs[4], (double*)bufs[5], (double*)bufs[6], (uint32_t*)bufs[7], nullptr));
+        HIP_TRY(hipMemcpy(hit, bufs[3], N, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(t, bufs[4], 8 * N, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(u, bufs[5], 8 * N, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(v, bufs[6], 8 * N, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(tri, bufs[7], 4 * N, hipMemcpyDeviceToHost));
+        return (int)RRT_OK;
+    });
+}
+
+int rrt_last_stats(const rrt_raytracer* rt_c, rrt_stats* out) {
+    return guarded([&]() -> int {
+        rrt_raytracer* rt = const_cast<rrt_raytracer*>(rt_c);
+        if (!rt || !out) throw Error{RRT_ERR_INVALID_ARG, "null argument"};
+        if (rt->stats_pending) {
+            DeviceGuard guard(rt->device);
+            HIP_TRY(hipEventSynchronize(rt->ev1));
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, rt->ev0, rt->ev1));
+            rt->stats.kernel_ms = ms;
+            rt->stats_pending = false;
+        }
+        *out = rt->stats;
+        return RRT_OK;
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,71 @@
+// device_scene.hpp -- layout of the scene in HBM and the host-side launch interface of the HIP kernels.
+//
+// Everything is uploaded once per raytracer (rrt_raytracer_create).  Layout choices:
+//  * geometry is stored in OWN-LIST SLOT ORDER: slot s = position in the concatenation of every node's
+//    `triangles` Vec (octree.rs:9) in node-id order, so a node's triangles are one contiguous run and the
+//    traversal needs no tri_index indirection (ray.rs:119-120).  orig[s] maps back to push order.
+//  * TriGeom keeps v1 and the two edges e1 = v2-v1, e2 = v3-v1.  The reference recomputes the edges on every
+//    test (ray.rs:60-61); a f64 subtraction gives the same bits whenever it is done, so they are precomputed.
+//  * one node is one 64-byte record: box + first_child + own run + occupancy flags of its 8 children, read with
+//    wave-uniform (scalar) loads.
+#pragma once
+#include <cstdint>
+
+namespace rrt {
+
+struct DevNode {                 // 64 B
+    double lo[3], hi[3];         // Aabb, aabb.rs:4-8
+    uint32_t first_child;        // 0 = leaf; children are first_child..first_child+7 (octree.rs:226-238)
+    uint32_t own_begin;          // first slot of this node's own triangles
+    uint32_t own_count;
+    uint32_t flags;              // bit k (0..7): child k has triangle_count > 0; bit 8: this node has triangle_count > 0 (ray.rs:112)
+};
+static_assert(sizeof(DevNode) == 64, "DevNode must be 64 bytes");
+
+struct DevTriGeom { double v1[3], e1[3], e2[3]; };                 // 72 B
+static_assert(sizeof(DevTriGeom) == 72, "DevTriGeom must be 72 bytes");
+
+struct DevTriAttr {                                                // 128 B: one cache line per shaded hit
+    double uv[6];                // t1.x,t1.y, t2.x,t2.y, t3.x,t3.y (raytracer.rs:45-50 read x,y only)
+    double nrm[9];               // n1, n2, n3
+    uint32_t mat, orig;          // material index; triangle index in push order
+};
+static_assert(sizeof(DevTriAttr) == 128, "DevTriAttr must be 128 bytes");
+
+struct DevMaterial { double ka[3], kd[3], ks[3], ns, kr; int32_t tex, bump; };   // material.rs:11-22
+struct DevTexture { const uint8_t* rgb; uint32_t width, height; };               // entities.rs:86-91
+struct DevLight { uint32_t kind, _pad; double intensity; double v[3]; };         // entities.rs:5-9
+
+#define RRT_MAX_LIGHTS 16
+#define RRT_MAX_REFLECT 8
+
+struct DevScene {                // passed to kernels by value (kernarg segment -> SGPRs)
+    const DevNode* nodes;
+    const DevTriGeom* geom;
+    const DevTriAttr* attr;
+    const DevMaterial* mats;
+    const DevTexture* tex;
+    uint32_t n_nodes, n_slots, n_mats, n_tex;
+    uint32_t n_lights, max_reflection_depth, stack_levels, _pad;
+    double origin[3];
+    double surface_offset;
+    DevLight lights[RRT_MAX_LIGHTS];
+};
+
+struct FrameParams {
+    uint32_t width, height;      // canvas size
+    double x_scale, y_scale, z_value;   // engine.rs:189-191
+    uint32_t tiles_x, tiles_y;   // 8x8-pixel tiles covering the canvas
+    uint32_t rank, world;        // tile k belongs to rank k % world
+    uint32_t tiled_output, _pad; // 0: out is the row-major framebuffer; 1: out is this rank's tile-major buffer
+};
+
+// kernel launches (render.hip).  All return hipError_t cast to int; stream is a hipStream_t.
+int launch_render(const DevScene& s, const FrameParams& f, uint32_t* d_out, void* stream);
+int launch_detile(uint32_t width, uint32_t height, uint32_t world, const uint32_t* d_gathered, uint32_t* d_fb, void* stream);
+int launch_ray_colours(const DevScene& s, uint32_t n, const double* d_origins, const double* d_dirs, uint32_t* d_colours, void* stream);
+int launch_intersect(const DevScene& s, uint32_t n, const double* d_origins, const double* d_dirs, const double* d_max_t,
+                     uint8_t* d_hit, double* d_t, double* d_u, double* d_v, uint32_t* d_tri, void* stream);
+uint32_t stack_bytes_per_wave(uint32_t levels);
+
+}  // namespace rrt

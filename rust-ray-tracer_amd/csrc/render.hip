@@ -1,0 +1,473 @@
+// render.hip -- the per-pixel hot path of conor722/rust-ray-tracer as hand-written HIP for gfx950 (MI355X).
+//
+// What runs here (reference file:line):
+//   Ray::intersect_aabb                       src/collision/ray.rs:21-54
+//   Ray::intersect_with_triangle              src/collision/ray.rs:56-94     (Moller-Trumbore, f64, no culling)
+//   Ray::intersect_with_octant_with_max_t     src/collision/ray.rs:104-168   (the "own list, then first child that hits" walk)
+//   RayTracer::get_ray_colour(_recursive)     src/scene/raytracer.rs:29-112
+//   get_normal_at_intersection                src/scene/raytracer.rs:114-162
+//   triangle_exists_between_points            src/scene/raytracer.rs:164-188
+//   compute_lighting_intensity/diffuse/spec   src/scene/raytracer.rs:192-304
+//   Scene::draw_scene pixel grid + put_pixel  src/scene/engine.rs:186-255, 146-158; Color::mix entities.rs:49-69
+//
+// Arithmetic is IEEE f64, op for op in the reference's order, compiled with -ffp-contract=off (Rust never fuses);
+// f64 divide and sqrt are correctly rounded on both sides; only pow() (raytracer.rs:295) may differ by an ulp.
+//
+// Execution model (MI355X-first, not a translation of the recursive CPU code):
+//   * one lane = one ray; one 64-lane wave = the 8x8 sub-sample rays of a 4x4-pixel tile; one wave per workgroup.
+//   * the recursion of ray.rs:104-168 is an explicit per-lane stack in LDS (own_t, own_slot, sorted-children word,
+//     first_child per level), laid out [level][field][lane] so every access is bank-conflict free.
+//   * the wave walks the octree NODE-COHERENTLY: each step picks one pending node (the first pending lane's), and
+//     every lane parked at that node processes it together.  Node record, the node's triangles and its children's
+//     boxes are then wave-uniform, so they are fetched with SCALAR loads (s_load via the constant address space)
+//     into SGPRs and cost no vector-memory traffic; VALU does only the f64 math.
+//   * primary, reflection and shadow rays share ONE traversal call site: each lane runs a small state machine
+//     (segment ray -> per-light shadow rays -> reflection) so lanes in different phases still traverse together.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "device_scene.hpp"
+
+namespace rrt {
+namespace {
+
+#define RRT_CONSTANT __attribute__((address_space(4)))
+constexpr double kEps = 2.220446049250313e-16;   // f64::EPSILON, ray.rs:66,89
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr double kInf = __builtin_huge_val();
+
+struct V3 { double x, y, z; };
+__device__ __forceinline__ V3 mk(double x, double y, double z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 ld3(const double* p) { return mk(p[0], p[1], p[2]); }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }   // engine.rs:16-26
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }   // engine.rs:36-46
+__device__ __forceinline__ V3 operator*(V3 a, double s) { return mk(a.x * s, a.y * s, a.z * s); }     // engine.rs:48-58
+__device__ __forceinline__ V3 operator/(V3 a, double s) { return mk(a.x / s, a.y / s, a.z / s); }     // engine.rs:72-82
+__device__ __forceinline__ V3 neg(V3 a) { return mk(-a.x, -a.y, -a.z); }                              // engine.rs:60-70
+__device__ __forceinline__ double dot(V3 a, V3 b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); } // engine.rs:85-87
+__device__ __forceinline__ double length(V3 a) { return sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }    // engine.rs:89-91
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {                                                     // engine.rs:93-99
+    return mk(a.y * b.z - a.z * b.y, -(a.x * b.z - a.z * b.x), a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ V3 normalised(V3 a) { return a / length(a); }                              // engine.rs:101-103
+
+// ------------------------------------------------------------------------------------------------ LDS stack
+// per wave: levels x 1280 B, level record = own_t[64] f64 | own_slot[64] u32 | meta[64] u32 | fc[64] u32
+constexpr uint32_t kLevelBytes = 64 * 8 + 3 * 64 * 4;
+struct Stack {
+    char* base; uint32_t lane;
+    __device__ __forceinline__ double& own_t(uint32_t l) const { return *reinterpret_cast<double*>(base + l * kLevelBytes + lane * 8); }
+    __device__ __forceinline__ uint32_t& own_slot(uint32_t l) const { return *reinterpret_cast<uint32_t*>(base + l * kLevelBytes + 512 + lane * 4); }
+    __device__ __forceinline__ uint32_t& meta(uint32_t l) const { return *reinterpret_cast<uint32_t*>(base + l * kLevelBytes + 768 + lane * 4); }
+    __device__ __forceinline__ uint32_t& fc(uint32_t l) const { return *reinterpret_cast<uint32_t*>(base + l * kLevelBytes + 1024 + lane * 4); }
+};
+
+// ------------------------------------------------------------------------------------------------ primitives
+// Ray::intersect_with_triangle, ray.rs:56-94, against a wave-uniform triangle (SGPR operands).  Returns t only; the
+// winning triangle's (u,v) are recomputed once per hit by mt_full (same arithmetic => same bits).
+__device__ __forceinline__ bool mt_uniform(const RRT_CONSTANT DevTriGeom* g, V3 o, V3 d, double& t_out) {
+    const double v1x = g->v1[0], v1y = g->v1[1], v1z = g->v1[2];
+    const double e1x = g->e1[0], e1y = g->e1[1], e1z = g->e1[2];
+    const double e2x = g->e2[0], e2y = g->e2[1], e2z = g->e2[2];
+    const double hx = d.y * e2z - d.z * e2y;
+    const double hy = -(d.x * e2z - d.z * e2x);
+    const double hz = d.x * e2y - d.y * e2x;
+    const double a = (e1x * hx + e1y * hy) + e1z * hz;
+    if (a > -kEps && a < kEps) return false;                   // ray.rs:66-69
+    const double f = 1.0 / a;
+    const double sx = o.x - v1x, sy = o.y - v1y, sz = o.z - v1z;
+    const double u = f * ((sx * hx + sy * hy) + sz * hz);
+    if (u < 0.0 || u > 1.0) return false;                      // ray.rs:75-77
+    const double qx = sy * e1z - sz * e1y;
+    const double qy = -(sx * e1z - sz * e1x);
+    const double qz = sx * e1y - sy * e1x;
+    const double v = f * ((d.x * qx + d.y * qy) + d.z * qz);
+    if (v < 0.0 || u + v > 1.0) return false;                  // ray.rs:82-84
+    const double t = f * ((e2x * qx + e2y * qy) + e2z * qz);
+    t_out = t;
+    return t > kEps;                                           // ray.rs:89-93
+}
+
+// same test on a per-lane triangle, returning u and v as well
+__device__ __forceinline__ bool mt_full(const DevTriGeom* g, V3 o, V3 d, double& t_out, double& u_out, double& v_out) {
+    const V3 v1 = ld3(g->v1), e1 = ld3(g->e1), e2 = ld3(g->e2);
+    const V3 h = cross(d, e2);
+    const double a = dot(e1, h);
+    if (a > -kEps && a < kEps) return false;
+    const double f = 1.0 / a;
+    const V3 s = o - v1;
+    const double u = f * dot(s, h);
+    if (u < 0.0 || u > 1.0) return false;
+    const V3 q = cross(s, e1);
+    const double v = f * dot(d, q);
+    if (v < 0.0 || u + v > 1.0) return false;
+    const double t = f * dot(e2, q);
+    t_out = t; u_out = u; v_out = v;
+    return t > kEps;
+}
+
+// Ray::intersect_aabb, ray.rs:21-54, against a wave-uniform box.  fmin/fmax == Rust f64::min/max (NaN-ignoring).
+__device__ __forceinline__ bool slab_uniform(const RRT_CONSTANT DevNode* b, V3 o, V3 d, double& t_out) {
+    const double t1 = (b->lo[0] - o.x) / d.x, t2 = (b->hi[0] - o.x) / d.x;
+    const double t3 = (b->lo[1] - o.y) / d.y, t4 = (b->hi[1] - o.y) / d.y;
+    const double t5 = (b->lo[2] - o.z) / d.z, t6 = (b->hi[2] - o.z) / d.z;
+    const double tmin = fmax(fmax(fmin(t1, t2), fmin(t3, t4)), fmin(t5, t6));
+    const double tmax = fmin(fmin(fmax(t1, t2), fmax(t3, t4)), fmax(t5, t6));
+    if (tmax < 0.0) return false;        // ray.rs:39-41
+    if (tmin > tmax) return false;       // ray.rs:44-46
+    t_out = (tmin < 0.0) ? tmax : tmin;  // ray.rs:49-53
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------ traversal
+// Ray::intersect_with_octant_with_max_t(octree, 0, max_t), ray.rs:104-168, for all 64 lanes at once.
+// Must be called from wave-uniform control flow; lanes with active == false take no part.
+// Result: slot == kNone <=> None; otherwise (t, slot) of the returned triangle.
+__device__ __forceinline__ void traverse(const DevScene& S, const Stack& stk, bool active, V3 o, V3 d, double max_t,
+                                         double& out_t, uint32_t& out_slot) {
+    bool done = !active;
+    uint32_t cur = 0;        // node this lane has to enter next
+    uint32_t sp = 0;         // number of frames on this lane's stack == depth of `cur`
+    double ret_t = kInf; uint32_t ret_slot = kNone;
+    const RRT_CONSTANT DevNode* nodes = (const RRT_CONSTANT DevNode*)S.nodes;
+    const RRT_CONSTANT DevTriGeom* geom = (const RRT_CONSTANT DevTriGeom*)S.geom;
+
+    for (;;) {
+        const unsigned long long pending = __ballot(!done);
+        if (pending == 0) break;
+        const int leader = __builtin_ctzll(pending);
+        const uint32_t unode = __builtin_amdgcn_readlane(cur, leader);   // wave-uniform node id
+        const RRT_CONSTANT DevNode* N = nodes + unode;
+        const uint32_t fc = N->first_child, ob = N->own_begin, oc = N->own_count, fl = N->flags;
+        if (!done && cur == unode) {
+            bool returning;
+            if (!(fl & 0x100u)) {                                        // triangle_count == 0 -> None, ray.rs:112-114
+                returning = true; ret_slot = kNone; ret_t = kInf;
+            } else {
+                double own_t = (sp == 0) ? max_t : kInf;                 // ray.rs:117 (children are entered with +inf, ray.rs:96-102,153)
+                uint32_t own_slot = kNone;
+                for (uint32_t s = 0; s < oc; ++s) {                      // ray.rs:119-129, list order, strict < keeps the first
+                    double t;
+                    if (mt_uniform(geom + ob + s, o, d, t) && t < own_t) { own_t = t; own_slot = ob + s; }
+                }
+                if (fc == 0) {                                           // leaf: no children -> returns its own result (ray.rs:163-167 with child_dist = inf)
+                    returning = true; ret_slot = own_slot; ret_t = own_t;
+                } else {
+                    // children: slab test in child order (ray.rs:135-144).  Children whose triangle_count is 0 return None at
+                    // once (ray.rs:112) and dropping entries does not disturb a stable sort, so they are skipped untested.
+                    double tk[8]; bool vk[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        vk[k] = false; tk[k] = kInf;
+                        if (fl & (1u << k)) {
+                            double t;
+                            if (slab_uniform(nodes + fc + k, o, d, t)) { vk[k] = true; tk[k] = (t != t) ? kInf : t; }   // NaN sorts last (reference panics, ray.rs:147)
+                        }
+                    }
+                    // stable ascending sort by t (ray.rs:146-147) as a rank computation
+                    uint32_t order = 0, n = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        uint32_t rank = 0;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            if (j == k) continue;
+                            const bool before = (j < k) ? (tk[j] <= tk[k]) : (tk[j] < tk[k]);
+                            rank += (vk[j] && before) ? 1u : 0u;
+                        }
+                        if (vk[k]) { order |= (uint32_t)k << (3u * rank); n++; }
+                    }
+                    stk.own_t(sp) = own_t; stk.own_slot(sp) = own_slot; stk.meta(sp) = order | (n << 24); stk.fc(sp) = fc;
+                    sp++;
+                    returning = false;
+                }
+            }
+            // unwind until this lane has a next node to enter or the root has returned (ray.rs:152-167)
+            for (;;) {
+                if (!returning) {
+                    const uint32_t m = stk.meta(sp - 1);
+                    const uint32_t cursor = m >> 28, n = (m >> 24) & 15u;
+                    if (cursor < n) {                                    // next sorted child, entered with max_t = +inf (ray.rs:153)
+                        stk.meta(sp - 1) = m + (1u << 28);
+                        cur = stk.fc(sp - 1) + ((m >> (3u * cursor)) & 7u);
+                        break;
+                    }
+                    ret_slot = stk.own_slot(sp - 1); ret_t = stk.own_t(sp - 1);   // no child hit: child_dist = inf -> own (ray.rs:163-167)
+                    sp--;
+                    returning = true;
+                }
+                if (sp == 0) { done = true; break; }
+                if (ret_slot != kNone) {                                 // a child returned Some -> `break` (ray.rs:155-160), then ray.rs:163-167
+                    const double pt = stk.own_t(sp - 1);
+                    if (!(ret_t < pt)) { ret_t = pt; ret_slot = stk.own_slot(sp - 1); }
+                    sp--;
+                } else {
+                    returning = false;                                   // child returned None -> try the next child
+                }
+            }
+        }
+    }
+    out_t = ret_t; out_slot = ret_slot;
+}
+
+// ------------------------------------------------------------------------------------------------ shading helpers
+__device__ __forceinline__ uint64_t f64_as_usize(double x) {   // Rust `as usize`: saturating, NaN -> 0 (raytracer.rs:52-53)
+    if (!(x > 0.0)) return 0;
+    if (x >= 18446744073709551616.0) return ~0ull;
+    return (uint64_t)x;
+}
+__device__ __forceinline__ uint32_t clamp_u8(double x) {       // clamp(0.0, 255.0) as u8 (raytracer.rs:97-108)
+    if (x < 0.0) x = 0.0;
+    if (x > 255.0) x = 255.0;
+    if (!(x > 0.0)) return 0;
+    return (uint32_t)x;
+}
+__device__ __forceinline__ V3 diffuse_term(double intensity, double n_dot_l, V3 normal, V3 l, V3 kd) {   // raytracer.rs:260-277
+    if (n_dot_l <= 0.0) return mk(0.0, 0.0, 0.0);
+    return ((kd * intensity) * n_dot_l) / (length(normal) * length(l));
+}
+__device__ __forceinline__ V3 specular_term(double sw, double intensity, V3 normal, V3 v, V3 l, V3 ks) { // raytracer.rs:279-304
+    if (sw != -1.0) {
+        const V3 r = ((normal * 2.0) * dot(normal, l)) - l;
+        const double r_dot_v = dot(r, v);
+        if (r_dot_v > 0.0) return (ks * intensity) * pow(r_dot_v / (length(r) * length(v)), sw);
+    }
+    return mk(0.0, 0.0, 0.0);
+}
+
+// RayTracer::get_ray_colour (raytracer.rs:29-112) for 64 lanes; wave-uniform call.  Returns 0x00RRGGBB.
+__device__ __forceinline__ uint32_t trace_colour(const DevScene& S, const Stack& stk, bool active, V3 origin, V3 direction) {
+    bool live = active;
+    bool in_shadow = false;                 // false: the ray in flight is a segment (primary/reflection) ray; true: a shadow ray
+    V3 ro = origin, rd = direction; double rmax = kInf;
+    V3 seg_d = direction;
+    V3 p = mk(0, 0, 0), n = mk(0, 0, 0), I = mk(0, 0, 0);
+    uint32_t col = 0, mat = 0, li = 0, depth = 0;
+    uint32_t term = 0x00FFFFFFu;            // colour of the last segment
+    double st_local[RRT_MAX_REFLECT][3]; double st_kr[RRT_MAX_REFLECT];
+
+    while (__any(live)) {
+        double t; uint32_t slot;
+        traverse(S, stk, live, ro, rd, rmax, t, slot);
+        if (live) {
+            const bool found = slot != kNone;
+            if (!in_shadow) {
+                if (!found) {
+                    term = 0x00FFFFFFu; live = false;                                    // WHITE, raytracer.rs:109-111
+                } else {
+                    // --- hit: raytracer.rs:39-57
+                    double u = 0, v = 0, t2;
+                    mt_full(S.geom + slot, ro, rd, t2, u, v);
+                    const DevTriAttr& A = S.attr[slot];
+                    seg_d = rd;
+                    p = ro + rd * t;                                                     // raytracer.rs:39
+                    mat = A.mat;
+                    const DevMaterial& M = S.mats[mat];
+                    const DevTexture T = S.tex[M.tex];
+                    const double w = 1.0 - u - v;                                        // raytracer.rs:43
+                    const double tex_x = A.uv[2] * u + A.uv[4] * v + A.uv[0] * w;        // raytracer.rs:45-47
+                    const double tex_y = A.uv[3] * u + A.uv[5] * v + A.uv[1] * w;        // raytracer.rs:48-50
+                    const uint64_t txi = f64_as_usize(tex_x * (double)T.width) % T.width;    // raytracer.rs:52
+                    const uint64_t tyi = f64_as_usize(tex_y * (double)T.height) % T.height;  // raytracer.rs:53
+                    const uint8_t* tp = T.rgb + 3ull * ((uint64_t)T.width * tyi + txi);  // raytracer.rs:55
+                    col = ((uint32_t)tp[0] << 16) | ((uint32_t)tp[1] << 8) | (uint32_t)tp[2];
+                    // get_normal_at_intersection, raytracer.rs:114-162
+                    V3 nn = (ld3(A.nrm + 3) * u + ld3(A.nrm + 6) * v) + ld3(A.nrm) * w;  // raytracer.rs:122-124
+                    if (M.bump >= 0) {
+                        const DevTexture B = S.tex[M.bump];
+                        const uint8_t* bp = B.rgb + 3ull * ((uint64_t)B.width * tyi + txi);  // raytracer.rs:127-128 (colour-texture indices, bump width)
+                        V3 bv = mk((double)bp[0], (double)bp[1], (double)bp[2]);
+                        bv = normalised(bv);
+                        bv = (bv * 2.0) - mk(1.0, 1.0, 1.0);                             // raytracer.rs:130-135
+                        V3 tg = cross(nn, mk(0.0, 1.0, 0.0));                            // raytracer.rs:137-141
+                        if (length(tg) == 0.0) tg = cross(nn, mk(0.0, 0.0, 1.0));        // raytracer.rs:143-149
+                        tg = normalised(tg);
+                        const V3 bt = normalised(cross(nn, tg));                         // raytracer.rs:152
+                        nn = mk(dot(bv, tg), dot(bv, bt), dot(bv, nn));                  // raytracer.rs:154-158
+                    }
+                    n = normalised(nn);                                                  // raytracer.rs:161
+                    I = mk(0.0, 0.0, 0.0); li = 0;                                       // compute_lighting_intensity, raytracer.rs:199-203
+                }
+            } else {
+                // --- result of the shadow ray for point light li, raytracer.rs:232-252
+                if (found) {
+                    li = S.n_lights;                                                     // `break` leaves the whole light loop, raytracer.rs:235-237
+                } else {
+                    const DevMaterial& M = S.mats[mat];
+                    const DevLight& L = S.lights[li];
+                    const V3 l = ld3(L.v) - p;
+                    const double n_dot_l = dot(n, l);
+                    I = I + diffuse_term(L.intensity, n_dot_l, n, l, ld3(M.kd));
+                    I = I + specular_term(M.ns, L.intensity, n, neg(seg_d), l, ld3(M.ks));
+                    li++;
+                }
+                in_shadow = false;
+            }
+            if (live) {
+                // --- continue the light loop (raytracer.rs:205-255) up to the next point light
+                const DevMaterial& M = S.mats[mat];
+                while (li < S.n_lights && !in_shadow) {
+                    const DevLight& L = S.lights[li];
+                    if (L.kind == 0u) {                                                  // Ambient, raytracer.rs:207-209
+                        I = I + ld3(M.ka) * L.intensity;
+                        li++;
+                    } else if (L.kind == 2u) {                                           // Directional, raytracer.rs:210-227
+                        const V3 dir = ld3(L.v);
+                        const double n_dot_l = dot(n, dir);
+                        I = I + diffuse_term(L.intensity, n_dot_l, n, dir, ld3(M.kd));
+                        I = I + specular_term(M.ns, L.intensity, n, neg(seg_d), dir, ld3(M.ks));
+                        li++;
+                    } else {                                                             // Point -> shadow ray, raytracer.rs:164-188
+                        const V3 dir = ld3(L.v) - p;
+                        ro = p + n * S.surface_offset;
+                        rd = dir;
+                        rmax = length(dir);
+                        in_shadow = true;
+                    }
+                }
+                if (!in_shadow) {
+                    // --- lights done: raytracer.rs:67-108
+                    const V3 local = mk((double)((col >> 16) & 255u) * I.x, (double)((col >> 8) & 255u) * I.y, (double)(col & 255u) * I.z);
+                    const double kr = M.kr;
+                    if (kr > 0.0 && depth < S.max_reflection_depth) {                    // raytracer.rs:76
+                        st_local[depth][0] = local.x; st_local[depth][1] = local.y; st_local[depth][2] = local.z; st_kr[depth] = kr;
+                        const double d_dot_n = dot(seg_d, n);
+                        rd = normalised(seg_d - (n * 2.0) * d_dot_n);                    // raytracer.rs:79
+                        ro = p + n * S.surface_offset;                                   // raytracer.rs:82
+                        rmax = kInf;
+                        depth++;
+                    } else {
+                        term = (clamp_u8(local.x) << 16) | (clamp_u8(local.y) << 8) | clamp_u8(local.z);   // raytracer.rs:104-108
+                        live = false;
+                    }
+                }
+            }
+        }
+    }
+    // unwind the reflection chain, innermost first (raytracer.rs:85-101): every level quantises to u8 before blending
+    uint32_t c = term;
+    for (uint32_t k = depth; k-- > 0;) {
+        const double kr = st_kr[k];
+        const double fx = st_local[k][0] * (1.0 - kr) + (double)((c >> 16) & 255u) * kr;
+        const double fy = st_local[k][1] * (1.0 - kr) + (double)((c >> 8) & 255u) * kr;
+        const double fz = st_local[k][2] * (1.0 - kr) + (double)(c & 255u) * kr;
+        c = (clamp_u8(fx) << 16) | (clamp_u8(fy) << 8) | clamp_u8(fz);
+    }
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------------ kernels
+// One wave per workgroup; workgroup b renders quadrant (b & 3) of this rank's local tile (b >> 2).
+__global__ __launch_bounds__(64) void render_kernel(const DevScene S, const FrameParams F, uint32_t* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const uint32_t lane = threadIdx.x;
+    const Stack stk{lds, lane};
+    const uint32_t local_tile = blockIdx.x >> 2, quad = blockIdx.x & 3u;
+    const uint32_t tile = local_tile * F.world + F.rank;
+    const uint32_t pix = lane >> 2, sub = lane & 3u;
+    const bool tile_ok = tile < F.tiles_x * F.tiles_y;
+    const uint32_t tx = tile_ok ? tile % F.tiles_x : 0, ty = tile_ok ? tile / F.tiles_x : 0;
+    const uint32_t px = tx * 8 + (quad & 1u) * 4 + (pix & 3u);
+    const uint32_t py = ty * 8 + (quad >> 1) * 4 + (pix >> 2);
+    const int32_t W = (int32_t)F.width, H = (int32_t)F.height;
+    // put_pixel (engine.rs:146-158): new_x = x + W/2, new_y = H - (y + H/2); draw_scene loops x in [-W/2, W/2), y in [-H/2, H/2)
+    // (engine.rs:198,205).  Pixels with no (x,y) in range stay 0 (Canvas::new, engine.rs:135): row 0 (rows 0,1 for odd H) and,
+    // for odd W, the last column.  The scene row y = -H/2 maps to new_y = H and is rejected (engine.rs:152-155), so it is not traced.
+    const bool in_fb = tile_ok && (int32_t)px < W && (int32_t)py < H;
+    const bool traced = in_fb && (int32_t)px < 2 * (W / 2) && (int32_t)py >= H - 2 * (H / 2) + 1;
+    const int32_t x = (int32_t)px - W / 2;
+    const int32_t y = (H - H / 2) - (int32_t)py;
+    const double xd = (sub & 1u) ? ((double)x + 0.5) : (double)x;                      // engine.rs:207-236: sub-samples (x,y),(x+.5,y),(x,y+.5),(x+.5,y+.5)
+    const double yd = (sub & 2u) ? ((double)y + 0.5) : (double)y;
+    const V3 dir = mk(xd * F.x_scale, yd * F.y_scale, F.z_value);
+    const uint32_t c = trace_colour(S, stk, traced, ld3(S.origin), dir);
+    // Color::mix over the 4 sub-samples of the pixel = 4 consecutive lanes (entities.rs:49-69): u64 sums, truncating /4
+    uint32_t r = (c >> 16) & 255u, g = (c >> 8) & 255u, b = c & 255u;
+    r += __shfl_xor(r, 1); g += __shfl_xor(g, 1); b += __shfl_xor(b, 1);
+    r += __shfl_xor(r, 2); g += __shfl_xor(g, 2); b += __shfl_xor(b, 2);
+    const uint32_t mixed = traced ? (((r >> 2) << 16) | ((g >> 2) << 8) | (b >> 2)) : 0u;   // Into<u32>, entities.rs:32-36
+    if (sub == 0) {
+        if (F.tiled_output) {
+            out[(size_t)local_tile * 64 + ((py & 7u) * 8 + (px & 7u))] = in_fb ? mixed : 0u;
+        } else if (in_fb) {
+            out[(size_t)py * F.width + px] = mixed;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void detile_kernel(uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t world, uint32_t tiles_per_rank,
+                                                     const uint32_t* __restrict__ gathered, uint32_t* __restrict__ fb) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= width * height) return;
+    const uint32_t px = i % width, py = i / width;
+    const uint32_t tile = (py >> 3) * tiles_x + (px >> 3);
+    const uint32_t r = tile % world, lt = tile / world;
+    fb[i] = gathered[((size_t)r * tiles_per_rank + lt) * 64 + ((py & 7u) * 8 + (px & 7u))];
+}
+
+__global__ __launch_bounds__(64) void ray_colour_kernel(const DevScene S, uint32_t n, const double* __restrict__ origins, const double* __restrict__ dirs,
+                                                        uint32_t* __restrict__ colours) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const Stack stk{lds, threadIdx.x};
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    const bool ok = i < n;
+    const V3 o = ok ? ld3(origins + 3 * (size_t)i) : mk(0, 0, 0), d = ok ? ld3(dirs + 3 * (size_t)i) : mk(0, 0, 1);
+    const uint32_t c = trace_colour(S, stk, ok, o, d);
+    if (ok) colours[i] = c;
+}
+
+__global__ __launch_bounds__(64) void intersect_kernel(const DevScene S, uint32_t n, const double* __restrict__ origins, const double* __restrict__ dirs,
+                                                       const double* __restrict__ max_t, uint8_t* __restrict__ hit, double* __restrict__ t_out,
+                                                       double* __restrict__ u_out, double* __restrict__ v_out, uint32_t* __restrict__ tri_out) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const Stack stk{lds, threadIdx.x};
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    const bool ok = i < n;
+    const V3 o = ok ? ld3(origins + 3 * (size_t)i) : mk(0, 0, 0), d = ok ? ld3(dirs + 3 * (size_t)i) : mk(0, 0, 1);
+    const double mt = (ok && max_t) ? max_t[i] : kInf;
+    double t; uint32_t slot;
+    traverse(S, stk, ok, o, d, mt, t, slot);
+    if (!ok) return;
+    if (slot == kNone) { hit[i] = 0; t_out[i] = 0; u_out[i] = 0; v_out[i] = 0; tri_out[i] = kNone; return; }
+    double t2, u = 0, v = 0;
+    mt_full(S.geom + slot, o, d, t2, u, v);
+    hit[i] = 1; t_out[i] = t; u_out[i] = u; v_out[i] = v; tri_out[i] = S.attr[slot].orig;
+}
+
+}  // namespace
+
+uint32_t stack_bytes_per_wave(uint32_t levels) { return levels * kLevelBytes; }
+
+int launch_render(const DevScene& s, const FrameParams& f, uint32_t* d_out, void* stream) {
+    const uint32_t n_tiles = f.tiles_x * f.tiles_y;
+    const uint32_t local_tiles = (n_tiles + f.world - 1) / f.world;
+    if (local_tiles == 0) return 0;
+    hipLaunchKernelGGL(render_kernel, dim3(local_tiles * 4), dim3(64), stack_bytes_per_wave(s.stack_levels), (hipStream_t)stream, s, f, d_out);
+    return (int)hipGetLastError();
+}
+
+int launch_detile(uint32_t width, uint32_t height, uint32_t world, const uint32_t* d_gathered, uint32_t* d_fb, void* stream) {
+    const uint32_t tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
+    const uint32_t tpr = (tiles_x * tiles_y + world - 1) / world;
+    const uint32_t n = width * height;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(detile_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, width, height, tiles_x, world, tpr, d_gathered, d_fb);
+    return (int)hipGetLastError();
+}
+
+int launch_ray_colours(const DevScene& s, uint32_t n, const double* d_origins, const double* d_dirs, uint32_t* d_colours, void* stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(ray_colour_kernel, dim3((n + 63) / 64), dim3(64), stack_bytes_per_wave(s.stack_levels), (hipStream_t)stream, s, n, d_origins, d_dirs, d_colours);
+    return (int)hipGetLastError();
+}
+
+int launch_intersect(const DevScene& s, uint32_t n, const double* d_origins, const double* d_dirs, const double* d_max_t,
+                     uint8_t* d_hit, double* d_t, double* d_u, double* d_v, uint32_t* d_tri, void* stream) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(intersect_kernel, dim3((n + 63) / 64), dim3(64), stack_bytes_per_wave(s.stack_levels), (hipStream_t)stream, s, n, d_origins, d_dirs,
+                       d_max_t, d_hit, d_t, d_u, d_v, d_tri);
+    return (int)hipGetLastError();
+}
+
+}  // namespace rrt
