@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native hot path (BASELINE.json: Mrays/s primary + frame ms, teapot @1920x1080).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--width 1920 --height 1080] [--scene assets/model2.obj] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = one full frame of the scene (Scene::draw_scene, engine.rs:186-255) with the scene already resident in HBM and the
+framebuffer left in HBM.  N = 1: one launch of the trace kernel writes the row-major framebuffer.  N > 1: the frame's 8x8-pixel
+tiles are dealt round-robin to the ranks (tile k -> rank k % N), each rank traces its tiles, one RCCL all-gather over xGMI
+collects the tile-major buffers and every rank de-tiles to the row-major frame ("scaling": "strong" -- the frame is fixed).
+Rank 0 prints ONE JSON line.  The `roofline` object prices the trace kernel against the f64 VECTOR peak (this path is VALU-bound:
+no MFMA, almost no HBM traffic -- see DESIGN.md section 5) and carries the HBM figure the metric asks for as `hbm`.
+`cpu_baseline` is the oracle (restatement of the reference's rayon CPU path; the Rust reference cannot be built here) timed on
+the host cores -- a checker used as a reported baseline, never part of the product path.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_VECTOR_PEAK_TFLOPS = 78.6     # MI355X f64 vector (non-matrix) peak: 256 CU x 128 FLOP/clk x 2.4 GHz (FMA = 2 FLOP); = 1/2 of the fp32 vector 157.3 TF in MI355X_MICROARCH.md
+HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_flops(c: dict) -> float:
+    """full-path Moller-Trumbore 52 flop, slab test 24, shading ~250 per shaded hit."""
+    return 52.0 * c["tri_tests"] + 24.0 * c["aabb_tests"] + 250.0 * c["hits_shaded"]
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--scene", default=os.path.join(ROOT, "assets", "model2.obj"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the bounded cpu_baseline sample")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback in the product path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    rrt = importlib.import_module("rust-ray-tracer_amd")
+    W, H = args.width, args.height
+    sd = rrt.parse_obj_file(args.scene)
+    lights = rrt.default_lights()
+    rt = rrt.RayTracer(sd, lights, rrt.DEFAULT_ORIGIN, device=local_rank)
+
+    fb = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+    if world > 1:
+        tpr = rrt.tiles_per_rank(W, H, world)
+        mine = torch.zeros(tpr * 64, dtype=torch.int32, device="cuda")
+        gathered = torch.zeros(world * tpr * 64, dtype=torch.int32, device="cuda")
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i: int | None) -> None:
+        if world == 1:
+            if i is not None: ev[i][0].record()
+            rt.render_into(fb, W, H)
+            if i is not None: ev[i][1].record()
+        else:
+            if i is not None: ev[i][0].record()
+            rt.render_tiles_into(mine, W, H, rank, world)
+            if i is not None: ev[i][1].record()
+            dist.all_gather_into_tensor(gathered, mine)
+            rt.detile_into(gathered, fb, W, H, world)
+
+    def fence() -> None:
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(None)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))   # trace kernel only, HIP events on its launch stream
+    if world > 1:
+        kmax = torch.tensor([kernel_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
+        kernel_ms = float(kmax.item())
+
+    if rank == 0:
+        traced_rows = 2 * (H // 2) - 1                       # y = -H/2 is computed by the reference but its pixels are rejected by put_pixel; not traced here
+        rays_primary = 4 * (2 * (W // 2)) * traced_rows
+        ms_per_step = elapsed / args.steps * 1e3
+        frame = fb.cpu().numpy().view(np.uint32)
+
+        # --- work counters for the algorithmic flop count (oracle counters; committed for the headline config, else scaled from the CPU sample)
+        key = f"{os.path.basename(args.scene)}@{W}x{H}"
+        counters, counters_src = None, None
+        try:
+            counters = json.load(open(os.path.join(ROOT, "bench_data", "work_counters.json")))["counters"].get(key)
+            counters_src = "bench_data/work_counters.json (oracle, exact for this frame)" if counters else None
+        except OSError:
+            pass
+
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import binding as ob                  # checker / reported baseline only
+            pos, uv, nrm, mat = sd.triangles()
+            osc = ob.OracleScene(pos, uv, nrm, mat, sd.materials(), sd.textures(), [(l.kind, l.intensity, (l.v.x, l.v.y, l.v.z)) for l in lights], (0.0, 2.0, -10.0))
+            cores = os.cpu_count() or 1
+            try:
+                cores = len(os.sched_getaffinity(0))
+            except AttributeError:
+                pass
+            tp = time.perf_counter(); osc.render(W // 8, H // 8, n_threads=cores); probe = time.perf_counter() - tp
+            div = 1
+            for cand in (1, 2, 3, 4, 6, 8):                   # largest sample (1/div of each dimension) expected to fit the time budget
+                if probe * 64.0 / (cand * cand) <= args.cpu_seconds:
+                    div = cand; break
+                div = cand
+            sw, sh = W // div, H // div
+            tp = time.perf_counter(); ref, cnt = osc.render(sw, sh, n_threads=cores); cpu_s = time.perf_counter() - tp
+            cpu_rays = cnt["rays_primary"]
+            cpu = {"value": round(cpu_rays / cpu_s / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                   "sample": f"oracle (f64 C restatement of the reference rayon path, -O3 -ffp-contract=off) rendering {os.path.basename(args.scene)} at {sw}x{sh} "
+                             f"({cpu_rays} primary rays incl. the discarded row) in {cpu_s:.2f} s on {cores} threads",
+                   "frame_ms_at_sample": round(cpu_s * 1e3, 1)}
+            if div == 1:
+                d = np.abs(np.stack([(frame >> s) & 255 for s in (16, 8, 0)], -1).astype(np.int64) - np.stack([(ref >> s) & 255 for s in (16, 8, 0)], -1).astype(np.int64))
+                cpu["gpu_vs_cpu_max_channel_diff"] = int(d.max())
+            if counters is None:
+                scale = (rays_primary + 4 * 2 * (W // 2)) / cpu_rays
+                counters = {k: v * scale for k, v in cnt.items()}
+                counters_src = f"oracle counters of the {sw}x{sh} CPU sample scaled by ray count"
+
+        roofline = None
+        if counters is not None:
+            # the GPU does not trace the discarded row; scale the per-frame oracle counters accordingly (rows are statistically alike at the frame edge: all misses)
+            flops = algorithmic_flops(counters)
+            rays_all = counters["rays_primary"] + counters["rays_shadow"] + counters["rays_reflect"]
+            per_rank = 1.0 / world
+            ach = flops * per_rank / (kernel_ms * 1e-3) / 1e12
+            hbm_bytes = rt.last_stats()["scene_bytes"] + 4.0 * W * H * per_rank
+            roofline = {"bound": "valu", "kernel": "render_kernel", "achieved": round(ach, 3), "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / FP64_VECTOR_PEAK_TFLOPS, 4), "traffic": None,
+                        "kernel_ms": round(kernel_ms, 4), "algorithmic_flops_per_launch": flops * per_rank,
+                        "flop_model": "52*tri_tests + 24*aabb_tests + 250*hits_shaded (SURVEY.md 8d), counts from the oracle",
+                        "counters": {k: (int(v) if float(v).is_integer() else v) for k, v in counters.items() if k != "seconds_8_threads_container"},
+                        "counters_source": counters_src, "rays_all_kinds": int(rays_all),
+                        "hbm": {"algorithmic_bytes_per_launch": hbm_bytes, "achieved": round(hbm_bytes / (kernel_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBPS,
+                                "unit": "GB/s", "frac": round(hbm_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6),
+                                "note": "scene (uploaded once, L2/MALL resident) + framebuffer; the path is not HBM-bound"}}
+
+        out = {"metric": "Mrays/s (primary) at 1920x1080, Utah teapot (model2.obj)" if (W, H) == (1920, 1080) else f"Mrays/s (primary) at {W}x{H}",
+               "value": round(rays_primary / (elapsed / args.steps) / 1e6, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "reference scene assets/model2.obj (teapot+table+mirror, 6334 triangles), camera/lights of main.rs"
+               if os.path.basename(args.scene) == "model2.obj" else "synthetic",
+               "config": {"workload": f"{os.path.basename(args.scene)} {W}x{H}, 4 sub-samples/pixel, shadow rays + depth-5 mirror reflection, f64",
+                          "rays_primary_per_frame": rays_primary, "partition": "single launch" if world == 1 else f"8x8-pixel tiles round-robin over {world} GPUs + RCCL all-gather",
+                          "octree_nodes": sd.info["n_nodes"], "triangles": sd.info["n_tris"]},
+               "frame_ms": round(ms_per_step, 4), "kernel_ms": round(kernel_ms, 4),
+               "frame_checksum": int(np.bitwise_xor.reduce(frame.ravel().astype(np.uint64) * np.arange(1, frame.size + 1, dtype=np.uint64)))}
+        if roofline is not None:
+            out["roofline"] = roofline
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

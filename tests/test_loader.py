@@ -1,0 +1,167 @@
+"""Host logic on the product side (no GPU): .obj/.mtl reader vs a line-by-line Python restatement of utils.rs, the octree builder vs the
+oracle's, the JPEG decoder vs an independent libjpeg (PIL), and the error codes that replace the reference's panics."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ASSETS, oracle_scene_for
+
+
+def py_parse_obj(path):
+    """Plain-Python restatement of parse_obj_file_lines / get_triangle (utils.rs:139-343) for geometry only."""
+    v, vt, vn, tris, mats, names = [], [], [], [], [], {}
+    cur = None
+    for line in open(path).read().split("\n"):
+        tok = line.split()
+        if not tok:
+            continue
+        if tok[0] == "mtllib":
+            k = 0
+            for ml in open(os.path.join(os.path.dirname(path), tok[1])).read().split("\n"):
+                mt = ml.split()
+                if mt and mt[0] == "newmtl":
+                    names[mt[1]] = k; k += 1
+        elif tok[0] == "usemtl":
+            cur = names[tok[1]]
+        elif tok[0] in ("v", "vt", "vn"):
+            vec = [float(tok[1]), float(tok[2]), float(tok[3]) if len(tok) > 3 else 0.0]
+            {"v": v, "vt": vt, "vn": vn}[tok[0]].append(vec)
+        elif tok[0] == "f":
+            P, T, N = [], [], []
+            for a in tok[1:4]:
+                parts = a.split("/")
+                P.append(v[int(parts[0]) - 1])
+                ti = int(parts[1]) - 1 if len(parts) > 1 else None
+                ni = int(parts[2]) - 1 if len(parts) > 2 else None
+                T.append(vt[ti] if ti is not None and 0 <= ti < len(vt) else [0.0, 0.0, 0.0])
+                N.append(vn[ni] if ni is not None and 0 <= ni < len(vn) else [0.0, 0.0, 0.0])
+            tris.append((P, T, N, cur))
+    pos = np.array([t[0] for t in tris]); uv = np.array([t[1] for t in tris]); nrm = np.array([t[2] for t in tris])
+    return pos, uv, nrm, np.array([t[3] for t in tris], np.uint32)
+
+
+@pytest.mark.parametrize("name,n_tris,n_nodes,root_own", [("model2.obj", 6334, 3265, 1110), ("model3.obj", 11532, 5593, 801), ("model.obj", 1004, 417, 472)])
+def test_loader_matches_python_restatement(rrt, name, n_tris, n_nodes, root_own):
+    sd = rrt.parse_obj_file(os.path.join(ASSETS, name))
+    pos, uv, nrm, mat = sd.triangles()
+    ppos, puv, pnrm, pmat = py_parse_obj(os.path.join(ASSETS, name))
+    assert pos.shape == (n_tris, 3, 3)
+    assert np.array_equal(pos, ppos) and np.array_equal(uv, puv) and np.array_equal(nrm, pnrm) and np.array_equal(mat, pmat)   # bit-exact f64 parse
+    assert sd.info["n_nodes"] == n_nodes and sd.info["root_own_count"] == root_own       # SURVEY.md 3.4 (probe numbers)
+
+
+def test_model_obj_drops_triangles_outside_root(rrt):
+    sd = rrt.parse_obj_file(os.path.join(ASSETS, "model.obj"))
+    assert sd.info["n_tris"] - sd.info["n_tris_in_tree"] == 8                             # mesh spans +-31 > +-20 root (octree.rs:71-73)
+
+
+def test_materials_and_textures(rrt, teapot):
+    m = teapot.materials()
+    assert [x["ns"] for x in m] == [240.0, 240.0, 240.0, 500.0] and m[3]["kr"] == 0.95 and m[3]["bump"] == -1 and m[3]["ka"] == (0.1, 0.1, 0.1)
+    assert m[3]["tex"] == m[0]["tex"]                       # mirror reuses metal.jpg through the per-file texture cache (utils.rs:87-95)
+    assert teapot.info["n_tex"] == 6                        # all materials of the .mtl are loaded, used or not
+    assert teapot.texture(0).shape == (1024, 1024, 3)
+
+
+@pytest.mark.parametrize("name", ["model2.obj", "model3.obj", "model.obj"])
+def test_octree_matches_oracle_build(rrt, ob, name):
+    sd = rrt.parse_obj_file(os.path.join(ASSETS, name))
+    a, b = sd.octree(), oracle_scene_for(ob, rrt, sd).octree()
+    for k in ("aabb", "first_child", "tri_count", "own_off", "own_idx"):
+        assert np.array_equal(a[k], b[k]), k
+    assert a["max_depth"] == b["max_depth"]
+
+
+def test_octree_from_arrays_random_soup_matches_oracle(rrt, ob):
+    syn = __import__("importlib").import_module("rust-ray-tracer_amd.synthetic")
+    verts, vt, nrm = syn.soup_arrays(3000, 0xABCDEF, s=0.3)
+    uv = np.concatenate([vt, np.zeros((3000, 3, 1))], -1); n3 = np.repeat(nrm[:, None, :], 3, 1)
+    mats = [dict(ka=(1, 1, 1), kd=(1, 1, 1), ks=(1, 1, 1), ns=240.0, kr=0.0, tex=0, bump=-1)]
+    tex = [np.zeros((4, 4, 3), np.uint8)]
+    sd = rrt.SceneData.from_arrays(verts, uv, n3, np.zeros(3000, np.uint32), mats, tex)
+    osc = ob.OracleScene(verts, uv, n3, np.zeros(3000, np.uint32), mats, tex, [(0, 1.0, (0, 0, 0))], (0, 2, -10))
+    a, b = sd.octree(), osc.octree()
+    for k in ("aabb", "first_child", "tri_count", "own_off", "own_idx"):
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_jpeg_decoder_matches_libjpeg(rrt):
+    """Build-owned baseline decoder vs PIL (libjpeg-turbo, islow IDCT): bit-exact on every scene texture.  This pins the decoder to the
+    IJG arithmetic; parity with the reference's zune-jpeg stays UNPINNED (no reference fixture holds decoded texels)."""
+    Image = pytest.importorskip("PIL.Image")
+    for name in ["metal.jpg", "metal_normal.jpg", "wood.jpg", "wood_normal.jpg", "dark_metal.jpg", "dark_metal_normal.jpg"]:
+        ours = rrt.decode_image_file(os.path.join(ASSETS, name))
+        ref = np.asarray(Image.open(os.path.join(ASSETS, name)).convert("RGB"))
+        assert np.array_equal(ours, ref), name
+
+
+def test_png_decoder(rrt, tmp_path):
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    p = tmp_path / "t.png"
+    Image.fromarray(img).save(p)
+    assert np.array_equal(rrt.decode_image_file(str(p)), img)
+    Image.fromarray(img).convert("P", palette=Image.ADAPTIVE).save(tmp_path / "p.png")
+    assert np.array_equal(rrt.decode_image_file(str(tmp_path / "p.png")), np.asarray(Image.open(tmp_path / "p.png").convert("RGB")))
+
+
+def _write(tmp_path, obj_text, mtl_text="newmtl m\nKa 1 1 1\nmap_Ka t.png\n"):
+    Image = pytest.importorskip("PIL.Image")
+    Image.fromarray(np.full((2, 2, 3), 128, np.uint8)).save(tmp_path / "t.png")
+    (tmp_path / "m.mtl").write_text(mtl_text)
+    (tmp_path / "s.obj").write_text(obj_text)
+    return str(tmp_path / "s.obj")
+
+
+def test_loader_defaults_and_quirks(rrt, tmp_path):
+    obj = "mtllib m.mtl\nusemtl m\nv 0 0 1\nv 1 0 1\nv 0 1\nvt 0.5 0.25\nvn 0 0 -1\nf 1/1/1 2/9/9 3\nf 1 2 3 garbage\n"
+    sd = rrt.parse_obj_file(_write(tmp_path, obj, "newmtl m\nKr 7\nmap_Ka t.png\nnewmtl unused\nmap_Ka t.png\nbump t.png\n"))
+    pos, uv, nrm, mat = sd.triangles()
+    assert pos[0].tolist() == [[0, 0, 1], [1, 0, 1], [0, 1, 0]]                  # missing z defaults to 0 (utils.rs:231)
+    assert uv[0].tolist() == [[0.5, 0.25, 0], [0, 0, 0], [0, 0, 0]]              # out-of-range / absent vt -> zero vector (utils.rs:285-306)
+    assert nrm[0].tolist() == [[0, 0, -1], [0, 0, 0], [0, 0, 0]]
+    m = sd.materials()
+    assert m[0]["kr"] == 1.0 and m[0]["ns"] == 240.0 and m[0]["ka"] == (0, 0, 0)   # Kr clamped (utils.rs:131), Ns default (utils.rs:60), Ka default
+    assert m[1]["bump"] == m[1]["tex"] == 0 and sd.info["n_tex"] == 1            # one decode per file name (utils.rs:87-109)
+
+
+@pytest.mark.parametrize("obj,mtl,status", [
+    ("mtllib m.mtl\nusemtl m\nv 0 0 0\nv 1 0 0\nf 1 2 3\n", None, "ERR_PARSE"),          # "No vertex with this index" (utils.rs:272-283)
+    ("mtllib m.mtl\nusemtl nope\n", None, "ERR_PARSE"),                                   # "Material not found" (utils.rs:184)
+    ("mtllib m.mtl\nusemtl m\nv 0 0 zero\n", None, "ERR_PARSE"),                          # "Could not parse value" (utils.rs:222)
+    ("mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n", None, "ERR_PARSE"),            # face before usemtl: unwrap on None (utils.rs:193)
+    ("mtllib m.mtl\nusemtl m\nv 0 0 0\nv 1 0 0\nv 0 1 0\nf 1//1 2//1 3//1\n", None, "ERR_PARSE"),   # '' is not a usize (utils.rs:246)
+    ("mtllib missing.mtl\n", None, "ERR_IO"),                                             # "Could not read file" (utils.rs:171)
+    ("mtllib m.mtl\n", "newmtl m\nKa 1 1 1\n", "ERR_PARSE"),                              # material without map_Ka: unwrap (utils.rs:61)
+    ("mtllib m.mtl\n", "newmtl m\nKa 2 0 0\nmap_Ka t.png\n", "ERR_PARSE"),                # coefficient outside [0,1]: assert! (utils.rs:373-376)
+    ("mtllib m.mtl\n", "newmtl m\nmap_Ka nothere.jpg\n", "ERR_IO"),                       # "Cannot read texture file" (utils.rs:346-347)
+])
+def test_loader_errors_are_status_codes(rrt, tmp_path, obj, mtl, status):
+    path = _write(tmp_path, obj) if mtl is None else _write(tmp_path, obj, mtl)
+    with pytest.raises(rrt.RrtError) as e:
+        rrt.parse_obj_file(path)
+    assert e.value.status == getattr(rrt, status), e.value
+
+
+def test_missing_obj_is_io_error(rrt):
+    with pytest.raises(rrt.RrtError) as e:
+        rrt.parse_obj_file("/nonexistent/file.obj")
+    assert e.value.status == rrt.ERR_IO
+
+
+def test_too_deep_octree_is_rejected(rrt):
+    p = [0.123456789, 1.718281828, 2.914159265]
+    tri = np.array([[p, p, p]] * 60, np.float64)     # 60 coincident point-triangles: each one opens a new level (octree.rs:79-92)
+    mats = [dict(ka=(1, 1, 1), kd=(1, 1, 1), ks=(1, 1, 1), ns=240.0, kr=0.0, tex=0, bump=-1)]
+    with pytest.raises(rrt.RrtError) as e:
+        rrt.SceneData.from_arrays(tri, np.zeros((60, 3, 3)), np.zeros((60, 3, 3)), np.zeros(60, np.uint32), mats, [np.zeros((1, 1, 3), np.uint8)])
+    assert e.value.status == rrt.ERR_DEPTH
+
+
+def test_soup_generator_is_deterministic(rrt):
+    syn = __import__("importlib").import_module("rust-ray-tracer_amd.synthetic")
+    assert syn.splitmix64(0, 3).tolist() == [0xE220A8397B1DCDAF, 0x6E789E6AA1B965F4, 0x06C45D188009454F]   # published splitmix64 test vector (seed 0)
+    a, _, _ = syn.soup_arrays(100, syn.SEED_100K); b, _, _ = syn.soup_arrays(100, syn.SEED_100K)
+    assert np.array_equal(a, b) and a[:, :, 1].min() > 0.4 and np.abs(a[:, :, 0]).max() < 4.6
