@@ -49,11 +49,16 @@ typedef struct { rrt_vec3 ka, kd, ks; double ns, kr; int32_t tex, bump; } rrt_ma
 /* == Texture, src/scene/entities.rs:86-91: RGB8, row-major, index = width*y + x (raytracer.rs:55) */
 typedef struct { const uint8_t *rgb; uint32_t width, height; } rrt_texture;
 
+/* RRT_FLAG_NO_CULL: walk every node's triangle list in full, in list order, exactly as ray.rs:119-129 does (no cluster boxes).
+ * Default (0): the lists are indexed by padded cluster boxes that skip triangles a ray cannot reach; results are identical
+ * (DESIGN.md section 4), tests compare the two modes bit for bit. */
+#define RRT_FLAG_NO_CULL 1u
+
 /* Render constants that the reference hard-codes; NULL => these defaults. */
 typedef struct {
     double surface_offset;            /* 1e-4, raytracer.rs:17 */
     uint32_t max_reflection_depth;    /* 5,    raytracer.rs:20 (<= 8 supported) */
-    uint32_t _pad;
+    uint32_t flags;                   /* 0, or RRT_FLAG_* */
     double vp_w, vp_h, vp_d;          /* 1,1,1 Viewport::default, engine.rs:113-119 */
 } rrt_options;
 

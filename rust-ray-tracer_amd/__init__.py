@@ -21,7 +21,7 @@ from typing import Iterable, Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librrt_hip.so")
+LIB_PATH = os.environ.get("RRT_LIB") or os.path.join(_HERE, "librrt_hip.so")   # RRT_LIB: developer override (e.g. the counters build)
 
 
 class RrtError(RuntimeError):
@@ -30,6 +30,8 @@ class RrtError(RuntimeError):
         self.status = status
         self.detail = detail
 
+
+FLAG_NO_CULL = 1   # RRT_FLAG_NO_CULL, include/rrt.h
 
 # status codes, include/rrt.h
 OK, ERR_INVALID_ARG, ERR_HIP, ERR_OOM, ERR_IO, ERR_PARSE, ERR_DEPTH, ERR_NO_DEVICE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7, -8
@@ -52,7 +54,7 @@ class CTexture(C.Structure):
 
 
 class COptions(C.Structure):
-    _fields_ = [("surface_offset", C.c_double), ("max_reflection_depth", C.c_uint32), ("_pad", C.c_uint32),
+    _fields_ = [("surface_offset", C.c_double), ("max_reflection_depth", C.c_uint32), ("flags", C.c_uint32),
                 ("vp_w", C.c_double), ("vp_h", C.c_double), ("vp_d", C.c_double)]
 
 
@@ -257,12 +259,13 @@ class RayTracer:
     """RayTracer{scene_data, lights, origin} (raytracer.rs:22-26), uploaded once to one MI355X."""
 
     def __init__(self, scene_data: SceneData, lights: Iterable[Light], origin: Vector3d = DEFAULT_ORIGIN, device: int = 0,
-                 surface_offset: float = 0.0001, max_reflection_depth: int = 5, viewport=(1.0, 1.0, 1.0)):
+                 surface_offset: float = 0.0001, max_reflection_depth: int = 5, viewport=(1.0, 1.0, 1.0), no_cull: bool = False):
+        """no_cull=True (RRT_FLAG_NO_CULL): walk every own list in full, in list order, as ray.rs:119-129; default uses the cluster boxes."""
         self.scene_data, self.lights, self.origin, self.device = scene_data, list(lights), origin, device
         cl = (CLight * max(1, len(self.lights)))()
         for i, l in enumerate(self.lights):
             cl[i] = CLight(l.kind, 0, float(l.intensity), l.v._c())
-        opt = COptions(surface_offset, max_reflection_depth, 0, *map(float, viewport))
+        opt = COptions(surface_offset, max_reflection_depth, FLAG_NO_CULL if no_cull else 0, *map(float, viewport))
         out = _P()
         _check(lib().rrt_raytracer_create(scene_data._h, cl, len(self.lights), origin._c(), C.byref(opt), device, C.byref(out)), "rrt_raytracer_create")
         self._h = out

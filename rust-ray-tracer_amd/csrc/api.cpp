@@ -270,7 +270,7 @@ int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n
         if (n_lights > RRT_MAX_LIGHTS) throw Error{RRT_ERR_INVALID_ARG, "too many lights (max 16)"};
         for (uint32_t i = 0; i < n_lights; i++) if (lights[i].kind > 2) throw Error{RRT_ERR_INVALID_ARG, "bad light kind"};
         rrt_options o;
-        if (opt) o = *opt; else { o.surface_offset = 0.0001; o.max_reflection_depth = 5; o._pad = 0; o.vp_w = o.vp_h = o.vp_d = 1.0; }
+        if (opt) o = *opt; else { o.surface_offset = 0.0001; o.max_reflection_depth = 5; o.flags = 0; o.vp_w = o.vp_h = o.vp_d = 1.0; }
         if (o.max_reflection_depth > RRT_MAX_REFLECT) throw Error{RRT_ERR_INVALID_ARG, "max_reflection_depth > 8"};
         int n_dev = 0;
         if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) { (void)hipGetLastError(); throw Error{RRT_ERR_NO_DEVICE, "no HIP device visible"}; }
@@ -280,28 +280,32 @@ int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n
         std::unique_ptr<rrt_raytracer, void (*)(rrt_raytracer*)> rt(new rrt_raytracer, rrt_raytracer_destroy);
         rt->device = device; rt->opt = o;
         const Model& M = m->m; const FlatOctree& T = M.tree;
-        const size_t n_nodes = T.box.size(), n_slots = T.own_idx.size();
+        const size_t n_nodes = T.box.size(), n_slots = T.own_idx.size();   // n_slots: every triangle in the tree appears in exactly one own list
 
+        ClusterSet CS;
+        build_clusters(M, !(o.flags & RRT_FLAG_NO_CULL), CS);
+        const size_t n_slots_c = CS.slot_tri.size();
         std::vector<DevNode> nodes(n_nodes);
         for (size_t i = 0; i < n_nodes; i++) {
             DevNode& d = nodes[i];
             for (int k = 0; k < 3; k++) { d.lo[k] = T.box[i].lo[k]; d.hi[k] = T.box[i].hi[k]; }
-            d.first_child = T.first_child[i]; d.own_begin = T.own_off[i]; d.own_count = T.own_off[i + 1] - T.own_off[i];
+            d.first_child = T.first_child[i]; d.sup_begin = CS.node_sup_begin[i]; d.sup_count = CS.node_sup_count[i];
             d.flags = T.tri_count[i] ? 0x100u : 0u;
             if (d.first_child) for (uint32_t k = 0; k < 8; k++) if (T.tri_count[d.first_child + k]) d.flags |= 1u << k;
         }
-        std::vector<DevTriGeom> geom(n_slots); std::vector<DevTriAttr> attr(n_slots);
-        for (size_t s = 0; s < n_slots; s++) {
-            const Triangle& t = M.triangles[T.own_idx[s]];
+        std::vector<DevTriGeom> geom(n_slots_c); std::vector<DevTriAttr> attr(n_slots_c);
+        for (size_t s = 0; s < n_slots_c; s++) {
+            const Triangle& t = M.triangles[CS.slot_tri[s]];
             DevTriGeom& g = geom[s];
             g.v1[0] = t.v1.x; g.v1[1] = t.v1.y; g.v1[2] = t.v1.z;
             g.e1[0] = t.v2.x - t.v1.x; g.e1[1] = t.v2.y - t.v1.y; g.e1[2] = t.v2.z - t.v1.z;   // ray.rs:60
             g.e2[0] = t.v3.x - t.v1.x; g.e2[1] = t.v3.y - t.v1.y; g.e2[2] = t.v3.z - t.v1.z;   // ray.rs:61
+            g.pos = CS.slot_pos[s]; g._pad = 0;
             DevTriAttr& a = attr[s];
             a.uv[0] = t.t1.x; a.uv[1] = t.t1.y; a.uv[2] = t.t2.x; a.uv[3] = t.t2.y; a.uv[4] = t.t3.x; a.uv[5] = t.t3.y;
             a.nrm[0] = t.n1.x; a.nrm[1] = t.n1.y; a.nrm[2] = t.n1.z; a.nrm[3] = t.n2.x; a.nrm[4] = t.n2.y; a.nrm[5] = t.n2.z;
             a.nrm[6] = t.n3.x; a.nrm[7] = t.n3.y; a.nrm[8] = t.n3.z;
-            a.mat = t.mat; a.orig = T.own_idx[s];
+            a.mat = t.mat; a.orig = CS.slot_tri[s];
         }
         std::vector<DevMaterial> mats(M.materials.size());
         for (size_t i = 0; i < mats.size(); i++) {
@@ -317,6 +321,10 @@ int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n
         DevScene& S = rt->scene;
         S.nodes = upload(rt.get(), nodes.data(), nodes.size());
         S.geom = upload(rt.get(), geom.data(), geom.size());
+        S.supers = upload(rt.get(), CS.supers.data(), CS.supers.size());
+        S.clusters = upload(rt.get(), CS.clusters.data(), CS.clusters.size());
+        S.cull_enabled = (o.flags & RRT_FLAG_NO_CULL) ? 0u : 1u;
+        S.cull_limit = (float)(CS.scene_magnitude * 4.0);
         S.attr = upload(rt.get(), attr.data(), attr.size());
         S.mats = upload(rt.get(), mats.data(), mats.size());
         S.tex = upload(rt.get(), texs.data(), texs.size());
@@ -328,6 +336,10 @@ int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n
             S.lights[i].kind = lights[i].kind; S.lights[i]._pad = 0; S.lights[i].intensity = lights[i].intensity;
             S.lights[i].v[0] = lights[i].v.x; S.lights[i].v[1] = lights[i].v.y; S.lights[i].v[2] = lights[i].v.z;
         }
+#ifdef RRT_PROFILE
+        { void* pb = nullptr; HIP_TRY(hipMalloc(&pb, 16 * sizeof(unsigned long long))); HIP_TRY(hipMemset(pb, 0, 16 * sizeof(unsigned long long)));
+          rt->allocs.push_back(pb); S.prof = static_cast<unsigned long long*>(pb); }
+#endif
         HIP_TRY(hipEventCreate(&rt->ev0)); HIP_TRY(hipEventCreate(&rt->ev1));
         HIP_TRY(hipDeviceSynchronize());
         *out = rt.release();
@@ -449,6 +461,19 @@ int rrt_intersect_rays(rrt_raytracer* rt, uint32_t n, const double* origins, con
         return (int)RRT_OK;
     });
 }
+
+#ifdef RRT_PROFILE
+// developer build only: read and clear the 16 work counters
+int rrt_prof_counters(rrt_raytracer* rt, unsigned long long* out16) {
+    return guarded([&]() -> int {
+        DeviceGuard guard(rt->device);
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(out16, rt->scene.prof, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemset(rt->scene.prof, 0, 16 * sizeof(unsigned long long)));
+        return RRT_OK;
+    });
+}
+#endif
 
 int rrt_last_stats(const rrt_raytracer* rt_c, rrt_stats* out) {
     return guarded([&]() -> int {

@@ -1,0 +1,118 @@
+// clusters.cpp -- result-preserving index over each node's OWN triangle list.
+//
+// The reference tests every triangle of a node's list and keeps the arg-min of t with the first list position winning ties
+// (src/collision/ray.rs:116-129).  That is an exact arg-min over a SET, so the triangles may be visited in any order and any
+// triangle the ray cannot hit may be skipped, provided ties are broken by the original list position.  Here each list is
+// cut into spatially compact clusters of <= kClusterTris triangles (median splits of the centroid bounds), clusters are grouped
+// into super-clusters of <= kSuperClusters clusters, and both carry a padded f32 bounding box that the kernel tests with a cheap
+// conservative fp32 slab test before touching the triangles.  Padding (kPadFraction of the scene magnitude, boxes rounded
+// outward) is >100x the fp32 error of that test; DESIGN.md section 4 states the exactness argument and its one caveat.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <numeric>
+
+#include "device_scene.hpp"
+#include "model.hpp"
+
+namespace rrt {
+namespace {
+
+constexpr uint32_t kClusterTris = 8;
+constexpr uint32_t kSuperClusters = 8;
+constexpr double kPadFraction = 1.0 / 32768.0;   // 2^-15 of the scene magnitude
+
+struct TriBox { double lo[3], hi[3], c[3]; };
+
+TriBox tri_box(const Triangle& t) {
+    TriBox b;
+    const double x[3][3] = {{t.v1.x, t.v2.x, t.v3.x}, {t.v1.y, t.v2.y, t.v3.y}, {t.v1.z, t.v2.z, t.v3.z}};
+    for (int k = 0; k < 3; k++) {
+        b.lo[k] = std::min(x[k][0], std::min(x[k][1], x[k][2]));
+        b.hi[k] = std::max(x[k][0], std::max(x[k][1], x[k][2]));
+        b.c[k] = (b.lo[k] + b.hi[k]) * 0.5;
+    }
+    return b;
+}
+
+float round_down(double x) { float f = (float)x; if ((double)f > x) f = std::nextafterf(f, -FLT_MAX); return std::isfinite(f) ? f : -FLT_MAX; }
+float round_up(double x) { float f = (float)x; if ((double)f < x) f = std::nextafterf(f, FLT_MAX); return std::isfinite(f) ? f : FLT_MAX; }
+
+// recursively split items[begin,end) (indices into `boxes`) until every part holds <= leaf items; emits [begin,end) ranges in order
+void split(std::vector<uint32_t>& items, size_t begin, size_t end, size_t leaf, const std::vector<TriBox>& boxes, std::vector<std::pair<size_t, size_t>>& out) {
+    if (end - begin <= leaf) { out.emplace_back(begin, end); return; }
+    double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+    for (size_t i = begin; i < end; i++) for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], boxes[items[i]].c[k]); hi[k] = std::max(hi[k], boxes[items[i]].c[k]); }
+    int axis = 0;
+    for (int k = 1; k < 3; k++) if (hi[k] - lo[k] > hi[axis] - lo[axis]) axis = k;
+    // split at a multiple of `leaf` nearest the middle so that parts fill up
+    size_t n = end - begin, parts = (n + leaf - 1) / leaf, left = (parts / 2) * leaf;
+    if (left == 0 || left >= n) left = n / 2;
+    std::nth_element(items.begin() + begin, items.begin() + begin + left, items.begin() + end, [&](uint32_t a, uint32_t b) {
+        const double ca = boxes[a].c[axis], cb = boxes[b].c[axis];
+        return ca < cb || (ca == cb && a < b);
+    });
+    split(items, begin, begin + left, leaf, boxes, out);
+    split(items, begin + left, end, leaf, boxes, out);
+}
+
+}  // namespace
+
+void build_clusters(const Model& m, bool enable_cull, ClusterSet& out) {
+    const FlatOctree& T = m.tree;
+    const size_t n_nodes = T.box.size();
+    out = ClusterSet{};
+    out.node_sup_begin.assign(n_nodes, 0); out.node_sup_count.assign(n_nodes, 0);
+    out.slot_tri.reserve(T.own_idx.size()); out.slot_pos.reserve(T.own_idx.size());
+
+    double mag = 0;
+    for (int k = 0; k < 3; k++) mag = std::max(mag, std::max(std::fabs(m.root.lo[k]), std::fabs(m.root.hi[k])));
+    out.scene_magnitude = mag;
+    const double pad = mag * kPadFraction;
+
+    std::vector<TriBox> boxes;
+    std::vector<uint32_t> items;
+    for (size_t node = 0; node < n_nodes; node++) {
+        const uint32_t b = T.own_off[node], e = T.own_off[node + 1];
+        out.node_sup_begin[node] = (uint32_t)out.supers.size();
+        if (b == e) continue;
+        const uint32_t n = e - b;
+        boxes.resize(n); items.resize(n);
+        for (uint32_t i = 0; i < n; i++) boxes[i] = tri_box(m.triangles[T.own_idx[b + i]]);
+        std::iota(items.begin(), items.end(), 0u);
+
+        std::vector<std::pair<size_t, size_t>> sup_ranges;
+        if (enable_cull) split(items, 0, n, (size_t)kClusterTris * kSuperClusters, boxes, sup_ranges);
+        else sup_ranges.emplace_back(0, n);
+        for (auto [sb, se] : sup_ranges) {
+            std::vector<std::pair<size_t, size_t>> cl_ranges;
+            if (enable_cull) split(items, sb, se, kClusterTris, boxes, cl_ranges);
+            else cl_ranges.emplace_back(sb, se);
+            DevSuper S{};
+            S.cl_begin = (uint32_t)out.clusters.size(); S.cl_count = (uint32_t)cl_ranges.size();
+            for (int k = 0; k < 3; k++) { S.lo[k] = FLT_MAX; S.hi[k] = -FLT_MAX; }
+            for (auto [cb, ce] : cl_ranges) {
+                std::sort(items.begin() + cb, items.begin() + ce);          // list order inside a cluster
+                DevCluster C{};
+                C.tri_begin = (uint32_t)out.slot_tri.size(); C.tri_count = (uint32_t)(ce - cb);
+                double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+                for (size_t i = cb; i < ce; i++) {
+                    const uint32_t it = items[i];
+                    for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], boxes[it].lo[k]); hi[k] = std::max(hi[k], boxes[it].hi[k]); }
+                    out.slot_tri.push_back(T.own_idx[b + it]);
+                    out.slot_pos.push_back(it);                              // position in the node's `triangles` Vec (ray.rs:119)
+                }
+                for (int k = 0; k < 3; k++) {
+                    C.lo[k] = enable_cull ? round_down(lo[k] - pad) : -FLT_MAX;
+                    C.hi[k] = enable_cull ? round_up(hi[k] + pad) : FLT_MAX;
+                    S.lo[k] = std::min(S.lo[k], C.lo[k]); S.hi[k] = std::max(S.hi[k], C.hi[k]);
+                }
+                out.clusters.push_back(C);
+            }
+            out.supers.push_back(S);
+        }
+        out.node_sup_count[node] = (uint32_t)out.supers.size() - out.node_sup_begin[node];
+    }
+}
+
+}  // namespace rrt

@@ -16,14 +16,19 @@ namespace rrt {
 struct DevNode {                 // 64 B
     double lo[3], hi[3];         // Aabb, aabb.rs:4-8
     uint32_t first_child;        // 0 = leaf; children are first_child..first_child+7 (octree.rs:226-238)
-    uint32_t own_begin;          // first slot of this node's own triangles
-    uint32_t own_count;
+    uint32_t sup_begin;          // first super-cluster of this node's own triangle list (clusters.cpp)
+    uint32_t sup_count;
     uint32_t flags;              // bit k (0..7): child k has triangle_count > 0; bit 8: this node has triangle_count > 0 (ray.rs:112)
 };
 static_assert(sizeof(DevNode) == 64, "DevNode must be 64 bytes");
 
-struct DevTriGeom { double v1[3], e1[3], e2[3]; };                 // 72 B
-static_assert(sizeof(DevTriGeom) == 72, "DevTriGeom must be 72 bytes");
+struct DevTriGeom { double v1[3], e1[3], e2[3]; uint32_t pos, _pad; };   // 80 B; pos = position in the node's own list (tie-break, ray.rs:124)
+static_assert(sizeof(DevTriGeom) == 80, "DevTriGeom must be 80 bytes");
+
+// own-list index (clusters.cpp): padded f32 boxes, rounded outward
+struct DevCluster { float lo[3], hi[3]; uint32_t tri_begin, tri_count; };   // 32 B: a run of <= 8 slots
+struct DevSuper { float lo[3], hi[3]; uint32_t cl_begin, cl_count; };       // 32 B: a run of <= 8 clusters
+static_assert(sizeof(DevCluster) == 32 && sizeof(DevSuper) == 32, "cluster records must be 32 bytes");
 
 struct DevTriAttr {                                                // 128 B: one cache line per shaded hit
     double uv[6];                // t1.x,t1.y, t2.x,t2.y, t3.x,t3.y (raytracer.rs:45-50 read x,y only)
@@ -42,6 +47,8 @@ struct DevLight { uint32_t kind, _pad; double intensity; double v[3]; };        
 struct DevScene {                // passed to kernels by value (kernarg segment -> SGPRs)
     const DevNode* nodes;
     const DevTriGeom* geom;
+    const DevSuper* supers;
+    const DevCluster* clusters;
     const DevTriAttr* attr;
     const DevMaterial* mats;
     const DevTexture* tex;
@@ -49,7 +56,12 @@ struct DevScene {                // passed to kernels by value (kernarg segment 
     uint32_t n_lights, max_reflection_depth, stack_levels, _pad;
     double origin[3];
     double surface_offset;
+    float cull_limit;            // rays with |origin| or |direction| components beyond this (or non-finite) skip the box culling
+    uint32_t cull_enabled;
     DevLight lights[RRT_MAX_LIGHTS];
+#ifdef RRT_PROFILE
+    unsigned long long* prof;    // developer build only (make prof): 16 wave-level work counters, see tools/profile_counters.py
+#endif
 };
 
 struct FrameParams {
@@ -67,5 +79,19 @@ int launch_ray_colours(const DevScene& s, uint32_t n, const double* d_origins, c
 int launch_intersect(const DevScene& s, uint32_t n, const double* d_origins, const double* d_dirs, const double* d_max_t,
                      uint8_t* d_hit, double* d_t, double* d_u, double* d_v, uint32_t* d_tri, void* stream);
 uint32_t stack_bytes_per_wave(uint32_t levels);
+
+}  // namespace rrt
+
+#include <vector>
+namespace rrt {
+struct Model;
+struct ClusterSet {
+    std::vector<DevSuper> supers;
+    std::vector<DevCluster> clusters;
+    std::vector<uint32_t> slot_tri, slot_pos;          // per device slot: triangle index in push order, position in its node's own list
+    std::vector<uint32_t> node_sup_begin, node_sup_count;
+    double scene_magnitude = 0;
+};
+void build_clusters(const Model& m, bool enable_cull, ClusterSet& out);
 
 }  // namespace rrt

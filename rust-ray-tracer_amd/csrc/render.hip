@@ -64,27 +64,60 @@ struct Stack {
 };
 
 // ------------------------------------------------------------------------------------------------ primitives
+// One triangle held in SGPRs (wave-uniform): v1 and the two precomputed edges.
+struct UTri { double v1x, v1y, v1z, e1x, e1y, e1z, e2x, e2y, e2z; uint32_t pos; };
+__device__ __forceinline__ UTri load_utri(const RRT_CONSTANT DevTriGeom* g) {
+    UTri t;
+    t.v1x = g->v1[0]; t.v1y = g->v1[1]; t.v1z = g->v1[2];
+    t.e1x = g->e1[0]; t.e1y = g->e1[1]; t.e1z = g->e1[2];
+    t.e2x = g->e2[0]; t.e2y = g->e2[1]; t.e2z = g->e2[2];
+    t.pos = g->pos;
+    return t;
+}
+
 // Ray::intersect_with_triangle, ray.rs:56-94, against a wave-uniform triangle (SGPR operands).  Returns t only; the
 // winning triangle's (u,v) are recomputed once per hit by mt_full (same arithmetic => same bits).
-__device__ __forceinline__ bool mt_uniform(const RRT_CONSTANT DevTriGeom* g, V3 o, V3 d, double& t_out) {
-    const double v1x = g->v1[0], v1y = g->v1[1], v1z = g->v1[2];
-    const double e1x = g->e1[0], e1y = g->e1[1], e1z = g->e1[2];
-    const double e2x = g->e2[0], e2y = g->e2[1], e2z = g->e2[2];
-    const double hx = d.y * e2z - d.z * e2y;
-    const double hy = -(d.x * e2z - d.z * e2x);
-    const double hz = d.x * e2y - d.y * e2x;
-    const double a = (e1x * hx + e1y * hy) + e1z * hz;
+//
+// The reference divides (f = 1.0/a, ray.rs:71) before its first rejection test, and an IEEE f64 divide costs as much as
+// everything before it.  Nearly every (ray, triangle) pair is rejected, so the rejections are decided here from the
+// NUMERATORS su = s.h, dq = d.q, eq = e2.q -- computed exactly as the reference computes them -- by conservative filters
+// that never reject a pair the reference accepts.  With f = fl(1/a) (sign of a; normal, relative error <= 2^-53, whenever
+// eps <= |a| < 1e100) and u = fl(f*su), v = fl(f*dq), t = fl(f*eq):
+//   (F1) sign(x) != sign(a), |x| > 1e-200, |a| < 1e100        =>  fl(f*x) is a non-zero negative number: u < 0 resp. v < 0.
+//   (F2) |x| > |a|*(1+2^-40)                                  =>  |fl(f*x)| > 1: u > 1 or u < 0; v > 1 (=> u+v > 1 as u >= 0) or v < 0.
+//   (F3) su, dq of a's sign and |su|+|dq| > |a|*(1+2^-30)     =>  fl(u+v) > 1.
+//   (F4) sign(eq) != sign(a)                                  =>  t <= 0, so `t > eps` fails.
+// Whatever the filters let through takes the reference's exact path (divide included), so borderline cases are decided by
+// the reference's own arithmetic.  NaNs fail every filter comparison and fall through to the exact path.
+constexpr double kC40 = 1.0 + 0x1p-40, kC30 = 1.0 + 0x1p-30;
+__device__ __forceinline__ bool mt_uniform(const UTri& g, V3 o, V3 d, double& t_out) {
+    const double hx = d.y * g.e2z - d.z * g.e2y;
+    const double hy = -(d.x * g.e2z - d.z * g.e2x);
+    const double hz = d.x * g.e2y - d.y * g.e2x;
+    const double a = (g.e1x * hx + g.e1y * hy) + g.e1z * hz;
     if (a > -kEps && a < kEps) return false;                   // ray.rs:66-69
+    const double sx = o.x - g.v1x, sy = o.y - g.v1y, sz = o.z - g.v1z;
+    const double su = (sx * hx + sy * hy) + sz * hz;
+    const double abs_a = fabs(a), abs_su = fabs(su);
+    const bool a_neg = a < 0.0, a_ok = abs_a < 1e100;
+    const double lim = abs_a * kC40;
+    if ((((su < 0.0) != a_neg) && abs_su > 1e-200 && a_ok) || abs_su > lim) return false;        // F1, F2 on u (ray.rs:75)
+    const double qx = sy * g.e1z - sz * g.e1y;
+    const double qy = -(sx * g.e1z - sz * g.e1x);
+    const double qz = sx * g.e1y - sy * g.e1x;
+    const double dq = (d.x * qx + d.y * qy) + d.z * qz;
+    const double abs_dq = fabs(dq);
+    if ((((dq < 0.0) != a_neg) && abs_dq > 1e-200 && a_ok) || abs_dq > lim) return false;        // F1, F2 on v (ray.rs:82)
+    if (((su < 0.0) == a_neg) && ((dq < 0.0) == a_neg) && (abs_su + abs_dq) > abs_a * kC30) return false;   // F3 on u+v (ray.rs:82)
+    const double eq = (g.e2x * qx + g.e2y * qy) + g.e2z * qz;
+    if ((eq < 0.0) != a_neg) return false;                     // F4 (ray.rs:89)
+    // exact path, ray.rs:71-93
     const double f = 1.0 / a;
-    const double sx = o.x - v1x, sy = o.y - v1y, sz = o.z - v1z;
-    const double u = f * ((sx * hx + sy * hy) + sz * hz);
+    const double u = f * su;
     if (u < 0.0 || u > 1.0) return false;                      // ray.rs:75-77
-    const double qx = sy * e1z - sz * e1y;
-    const double qy = -(sx * e1z - sz * e1x);
-    const double qz = sx * e1y - sy * e1x;
-    const double v = f * ((d.x * qx + d.y * qy) + d.z * qz);
+    const double v = f * dq;
     if (v < 0.0 || u + v > 1.0) return false;                  // ray.rs:82-84
-    const double t = f * ((e2x * qx + e2y * qy) + e2z * qz);
+    const double t = f * eq;
     t_out = t;
     return t > kEps;                                           // ray.rs:89-93
 }
@@ -120,11 +153,48 @@ __device__ __forceinline__ bool slab_uniform(const RRT_CONSTANT DevNode* b, V3 o
     return true;
 }
 
+// ------------------------------------------------------------------------------------------------ own-list index: fp32 box filter
+// The ray in fp32 for the conservative box filter over the cluster boxes of clusters.cpp: t = lo*inv - o*inv per slab as one FMA.
+// A direction component smaller than 1e-20 is treated as parallel (inv = 1e30): over any t that matters the ray does not move along
+// that axis by more than the box padding.  Rays with non-finite or out-of-scale components skip the filter (`nocull`).
+struct Ray32 { float ix, iy, iz, nx, ny, nz; bool nocull; };
+__device__ __forceinline__ Ray32 make_ray32(V3 o, V3 d, float limit, bool enabled) {
+    const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z, dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
+    Ray32 r;
+    r.nocull = !(enabled && fabsf(ox) < limit && fabsf(oy) < limit && fabsf(oz) < limit && fabsf(dx) < limit && fabsf(dy) < limit && fabsf(dz) < limit);
+    r.ix = fabsf(dx) < 1e-20f ? 1e30f : 1.0f / dx;
+    r.iy = fabsf(dy) < 1e-20f ? 1e30f : 1.0f / dy;
+    r.iz = fabsf(dz) < 1e-20f ? 1e30f : 1.0f / dz;
+    r.nx = -ox * r.ix; r.ny = -oy * r.iy; r.nz = -oz * r.iz;
+    return r;
+}
+// true unless the ray (t >= 0) certainly misses the padded box; lo/hi are wave-uniform
+__device__ __forceinline__ bool slab32(const float lox, const float loy, const float loz, const float hix, const float hiy, const float hiz, const Ray32& r) {
+    const float ax = __builtin_fmaf(lox, r.ix, r.nx), bx = __builtin_fmaf(hix, r.ix, r.nx);
+    const float ay = __builtin_fmaf(loy, r.iy, r.ny), by = __builtin_fmaf(hiy, r.iy, r.ny);
+    const float az = __builtin_fmaf(loz, r.iz, r.nz), bz = __builtin_fmaf(hiz, r.iz, r.nz);
+    const float tmin = fmaxf(fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)), 0.0f);
+    const float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    return r.nocull || tmin <= tmax;
+}
+
+// ------------------------------------------------------------------------------------------------ developer counters
+#ifdef RRT_PROFILE
+struct Prof { unsigned long long c[16]; };
+#define PROF_DECL Prof& prof,
+#define PROF_ARG prof,
+#define PROF_ADD(i, x) (prof.c[i] += (unsigned long long)(x))
+#else
+#define PROF_DECL
+#define PROF_ARG
+#define PROF_ADD(i, x) ((void)0)
+#endif
+
 // ------------------------------------------------------------------------------------------------ traversal
 // Ray::intersect_with_octant_with_max_t(octree, 0, max_t), ray.rs:104-168, for all 64 lanes at once.
 // Must be called from wave-uniform control flow; lanes with active == false take no part.
 // Result: slot == kNone <=> None; otherwise (t, slot) of the returned triangle.
-__device__ __forceinline__ void traverse(const DevScene& S, const Stack& stk, bool active, V3 o, V3 d, double max_t,
+__device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stack& stk, bool active, V3 o, V3 d, double max_t,
                                          double& out_t, uint32_t& out_slot) {
     bool done = !active;
     uint32_t cur = 0;        // node this lane has to enter next
@@ -132,14 +202,19 @@ __device__ __forceinline__ void traverse(const DevScene& S, const Stack& stk, bo
     double ret_t = kInf; uint32_t ret_slot = kNone;
     const RRT_CONSTANT DevNode* nodes = (const RRT_CONSTANT DevNode*)S.nodes;
     const RRT_CONSTANT DevTriGeom* geom = (const RRT_CONSTANT DevTriGeom*)S.geom;
+    const RRT_CONSTANT DevSuper* supers = (const RRT_CONSTANT DevSuper*)S.supers;
+    const RRT_CONSTANT DevCluster* clusters = (const RRT_CONSTANT DevCluster*)S.clusters;
+    const Ray32 r32 = make_ray32(o, d, S.cull_limit, S.cull_enabled != 0);
 
+    PROF_ADD(6, 1); PROF_ADD(7, __popcll(__ballot(active)));
     for (;;) {
         const unsigned long long pending = __ballot(!done);
         if (pending == 0) break;
+        PROF_ADD(0, 1); PROF_ADD(1, __popcll(__ballot(!done && cur == (uint32_t)__builtin_amdgcn_readlane(cur, __builtin_ctzll(pending)))));
         const int leader = __builtin_ctzll(pending);
         const uint32_t unode = __builtin_amdgcn_readlane(cur, leader);   // wave-uniform node id
         const RRT_CONSTANT DevNode* N = nodes + unode;
-        const uint32_t fc = N->first_child, ob = N->own_begin, oc = N->own_count, fl = N->flags;
+        const uint32_t fc = N->first_child, sb = N->sup_begin, sc = N->sup_count, fl = N->flags;
         if (!done && cur == unode) {
             bool returning;
             if (!(fl & 0x100u)) {                                        // triangle_count == 0 -> None, ray.rs:112-114
@@ -147,9 +222,30 @@ __device__ __forceinline__ void traverse(const DevScene& S, const Stack& stk, bo
             } else {
                 double own_t = (sp == 0) ? max_t : kInf;                 // ray.rs:117 (children are entered with +inf, ray.rs:96-102,153)
                 uint32_t own_slot = kNone;
-                for (uint32_t s = 0; s < oc; ++s) {                      // ray.rs:119-129, list order, strict < keeps the first
-                    double t;
-                    if (mt_uniform(geom + ob + s, o, d, t) && t < own_t) { own_t = t; own_slot = ob + s; }
+                uint32_t own_pos = 0;
+                // ray.rs:119-129 as an arg-min over the list: super-cluster boxes -> cluster boxes -> triangles.  A later list position never
+                // replaces an equal t (strict < in the reference keeps the first), so ties go to the smaller `pos`.
+                for (uint32_t si = 0; si < sc; ++si) {
+                    const RRT_CONSTANT DevSuper* SP = supers + sb + si;
+                    const uint32_t cb = SP->cl_begin, cc = SP->cl_count;
+                    const bool hs = slab32(SP->lo[0], SP->lo[1], SP->lo[2], SP->hi[0], SP->hi[1], SP->hi[2], r32);
+                    PROF_ADD(10, 1);
+                    if (__ballot(hs) == 0) continue;
+                    for (uint32_t ci = 0; ci < cc; ++ci) {
+                        const RRT_CONSTANT DevCluster* CP = clusters + cb + ci;
+                        const uint32_t tb = CP->tri_begin, tc = CP->tri_count;
+                        const bool hc = hs && slab32(CP->lo[0], CP->lo[1], CP->lo[2], CP->hi[0], CP->hi[1], CP->hi[2], r32);
+                        PROF_ADD(11, 1);
+                        if (__ballot(hc) == 0) continue;
+                        UTri cur = load_utri(geom + tb);
+                        for (uint32_t s = 0; s < tc; ++s) {
+                            const UTri nxt = load_utri(geom + tb + ((s + 1 < tc) ? s + 1 : s));   // scalar prefetch of the next triangle
+                            double t;
+                            PROF_ADD(2, 1); PROF_ADD(3, __popcll(__ballot(hc)));
+                            if (hc && mt_uniform(cur, o, d, t) && (t < own_t || (t == own_t && cur.pos < own_pos))) { own_t = t; own_slot = tb + s; own_pos = cur.pos; }
+                            cur = nxt;
+                        }
+                    }
                 }
                 if (fc == 0) {                                           // leaf: no children -> returns its own result (ray.rs:163-167 with child_dist = inf)
                     returning = true; ret_slot = own_slot; ret_t = own_t;
@@ -162,6 +258,7 @@ __device__ __forceinline__ void traverse(const DevScene& S, const Stack& stk, bo
                         vk[k] = false; tk[k] = kInf;
                         if (fl & (1u << k)) {
                             double t;
+                            PROF_ADD(8, 1); PROF_ADD(9, __popcll(__ballot(1)));
                             if (slab_uniform(nodes + fc + k, o, d, t)) { vk[k] = true; tk[k] = (t != t) ? kInf : t; }   // NaN sorts last (reference panics, ray.rs:147)
                         }
                     }
@@ -237,7 +334,7 @@ __device__ __forceinline__ V3 specular_term(double sw, double intensity, V3 norm
 }
 
 // RayTracer::get_ray_colour (raytracer.rs:29-112) for 64 lanes; wave-uniform call.  Returns 0x00RRGGBB.
-__device__ __forceinline__ uint32_t trace_colour(const DevScene& S, const Stack& stk, bool active, V3 origin, V3 direction) {
+__device__ __forceinline__ uint32_t trace_colour(PROF_DECL const DevScene& S, const Stack& stk, bool active, V3 origin, V3 direction) {
     bool live = active;
     bool in_shadow = false;                 // false: the ray in flight is a segment (primary/reflection) ray; true: a shadow ray
     V3 ro = origin, rd = direction; double rmax = kInf;
@@ -249,7 +346,7 @@ __device__ __forceinline__ uint32_t trace_colour(const DevScene& S, const Stack&
 
     while (__any(live)) {
         double t; uint32_t slot;
-        traverse(S, stk, live, ro, rd, rmax, t, slot);
+        traverse(PROF_ARG S, stk, live, ro, rd, rmax, t, slot);
         if (live) {
             const bool found = slot != kNone;
             if (!in_shadow) {
@@ -359,7 +456,7 @@ __device__ __forceinline__ uint32_t trace_colour(const DevScene& S, const Stack&
 
 // ------------------------------------------------------------------------------------------------ kernels
 // One wave per workgroup; workgroup b renders quadrant (b & 3) of this rank's local tile (b >> 2).
-__global__ __launch_bounds__(64) void render_kernel(const DevScene S, const FrameParams F, uint32_t* __restrict__ out) {
+__global__ __launch_bounds__(64, 3) void render_kernel(const DevScene S, const FrameParams F, uint32_t* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const uint32_t lane = threadIdx.x;
     const Stack stk{lds, lane};
@@ -381,7 +478,13 @@ __global__ __launch_bounds__(64) void render_kernel(const DevScene S, const Fram
     const double xd = (sub & 1u) ? ((double)x + 0.5) : (double)x;                      // engine.rs:207-236: sub-samples (x,y),(x+.5,y),(x,y+.5),(x+.5,y+.5)
     const double yd = (sub & 2u) ? ((double)y + 0.5) : (double)y;
     const V3 dir = mk(xd * F.x_scale, yd * F.y_scale, F.z_value);
-    const uint32_t c = trace_colour(S, stk, traced, ld3(S.origin), dir);
+#ifdef RRT_PROFILE
+    Prof prof{};
+#endif
+    const uint32_t c = trace_colour(PROF_ARG S, stk, traced, ld3(S.origin), dir);
+#ifdef RRT_PROFILE
+    if (lane == 0) for (int i = 0; i < 16; i++) if (prof.c[i]) atomicAdd(S.prof + i, prof.c[i]);
+#endif
     // Color::mix over the 4 sub-samples of the pixel = 4 consecutive lanes (entities.rs:49-69): u64 sums, truncating /4
     uint32_t r = (c >> 16) & 255u, g = (c >> 8) & 255u, b = c & 255u;
     r += __shfl_xor(r, 1); g += __shfl_xor(g, 1); b += __shfl_xor(b, 1);
@@ -413,7 +516,10 @@ __global__ __launch_bounds__(64) void ray_colour_kernel(const DevScene S, uint32
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     const bool ok = i < n;
     const V3 o = ok ? ld3(origins + 3 * (size_t)i) : mk(0, 0, 0), d = ok ? ld3(dirs + 3 * (size_t)i) : mk(0, 0, 1);
-    const uint32_t c = trace_colour(S, stk, ok, o, d);
+#ifdef RRT_PROFILE
+    Prof prof{};
+#endif
+    const uint32_t c = trace_colour(PROF_ARG S, stk, ok, o, d);
     if (ok) colours[i] = c;
 }
 
@@ -427,7 +533,10 @@ __global__ __launch_bounds__(64) void intersect_kernel(const DevScene S, uint32_
     const V3 o = ok ? ld3(origins + 3 * (size_t)i) : mk(0, 0, 0), d = ok ? ld3(dirs + 3 * (size_t)i) : mk(0, 0, 1);
     const double mt = (ok && max_t) ? max_t[i] : kInf;
     double t; uint32_t slot;
-    traverse(S, stk, ok, o, d, mt, t, slot);
+#ifdef RRT_PROFILE
+    Prof prof{};
+#endif
+    traverse(PROF_ARG S, stk, ok, o, d, mt, t, slot);
     if (!ok) return;
     if (slot == kNone) { hit[i] = 0; t_out[i] = 0; u_out[i] = 0; v_out[i] = 0; tri_out[i] = kNone; return; }
     double t2, u = 0, v = 0;

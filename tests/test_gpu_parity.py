@@ -108,6 +108,25 @@ def test_options_viewport_offset_depth(rrt, teapot, ob):
     assert rt.render(96, 64).shape == (64, 96)
 
 
+@pytest.mark.parametrize("name,w,h", [("model2.obj", 640, 480), ("model2.obj", 1920, 1080), ("model3.obj", 480, 360), ("model.obj", 333, 211)])
+def test_cluster_index_is_result_preserving(rrt, name, w, h):
+    """Default mode (padded cluster boxes over every own list, clusters.cpp) vs RRT_FLAG_NO_CULL (every list walked in full, in list
+    order, as ray.rs:119-129): frames must be IDENTICAL, at configs[0]/configs[1] sizes too; likewise t/u/v/triangle of random rays."""
+    sd = rrt.parse_obj_file(os.path.join(ASSETS, name))
+    fast = rrt.RayTracer(sd, rrt.default_lights()); exact = rrt.RayTracer(sd, rrt.default_lights(), no_cull=True)
+    assert np.array_equal(fast.render(w, h), exact.render(w, h))
+    rng = np.random.default_rng(11)
+    n = 20000
+    o = rng.uniform([-5, -0.5, -8], [5, 6, 5], (n, 3)); d = rng.normal(size=(n, 3)); d[:500, rng.integers(0, 3)] = 0.0
+    mt = rng.uniform(0.5, 40.0, n); mt[::3] = np.inf
+    a = fast.intersect_rays(o, d, mt); b = exact.intersect_rays(o, d, mt)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    big = rrt.RayTracer(sd, rrt.default_lights(), rrt.Vector3d(1e4, 2.0, -10.0))       # origin beyond the fp32 filter's scale limit: filter must switch itself off
+    big_exact = rrt.RayTracer(sd, rrt.default_lights(), rrt.Vector3d(1e4, 2.0, -10.0), no_cull=True)
+    assert np.array_equal(big.render(64, 48), big_exact.render(64, 48))
+
+
 def test_tile_partition_reassembles_frame(rrt, teapot_rt):
     """Multi-GPU path on one GPU: every rank's tile buffer rendered separately, gathered, de-tiled == single-launch frame (bit-exact)."""
     torch = pytest.importorskip("torch")
