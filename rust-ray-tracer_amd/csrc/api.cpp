@@ -288,13 +288,19 @@ int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n
         std::vector<DevNode> nodes(n_nodes);
         for (size_t i = 0; i < n_nodes; i++) {
             DevNode& d = nodes[i];
-            for (int k = 0; k < 3; k++) { d.lo[k] = T.box[i].lo[k]; d.hi[k] = T.box[i].hi[k]; }
+            for (int k = 0; k < 3; k++) {
+                d.lo[k] = T.box[i].lo[k]; d.hi[k] = T.box[i].hi[k];
+                // the split plane: child TFR (index 6, octree.rs:216-225) has lo == mid on every axis; for a leaf recompute it as subdivide would
+                d.mid[k] = T.first_child[i] ? T.box[T.first_child[i] + 6].lo[k] : d.lo[k] + (d.hi[k] - d.lo[k]) / 2.0;
+            }
             d.first_child = T.first_child[i]; d.sup_begin = CS.node_sup_begin[i]; d.sup_count = CS.node_sup_count[i];
+            d.s0_begin = d.sup_count ? CS.supers[d.sup_begin].tri_begin : 0; d.s0_count = d.sup_count ? CS.supers[d.sup_begin].tri_count : 0;
             d.flags = T.tri_count[i] ? 0x100u : 0u;
             if (d.first_child) for (uint32_t k = 0; k < 8; k++) if (T.tri_count[d.first_child + k]) d.flags |= 1u << k;
         }
         std::vector<DevTriGeom> geom(n_slots_c); std::vector<DevTriAttr> attr(n_slots_c);
         for (size_t s = 0; s < n_slots_c; s++) {
+            if (CS.slot_tri[s] == kPadSlot) { std::memset(&geom[s], 0, sizeof(DevTriGeom)); std::memset(&attr[s], 0, sizeof(DevTriAttr)); attr[s].orig = kPadSlot; continue; }
             const Triangle& t = M.triangles[CS.slot_tri[s]];
             DevTriGeom& g = geom[s];
             g.v1[0] = t.v1.x; g.v1[1] = t.v1.y; g.v1[2] = t.v1.z;
@@ -322,7 +328,7 @@ int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n
         S.nodes = upload(rt.get(), nodes.data(), nodes.size());
         S.geom = upload(rt.get(), geom.data(), geom.size());
         S.supers = upload(rt.get(), CS.supers.data(), CS.supers.size());
-        S.clusters = upload(rt.get(), CS.clusters.data(), CS.clusters.size());
+        S.cboxes = upload(rt.get(), CS.cboxes.data(), CS.cboxes.size());
         S.cull_enabled = (o.flags & RRT_FLAG_NO_CULL) ? 0u : 1u;
         S.cull_limit = (float)(CS.scene_magnitude * 4.0);
         S.attr = upload(rt.get(), attr.data(), attr.size());

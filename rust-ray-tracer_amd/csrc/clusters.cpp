@@ -83,18 +83,21 @@ void build_clusters(const Model& m, bool enable_cull, ClusterSet& out) {
 
         std::vector<std::pair<size_t, size_t>> sup_ranges;
         if (enable_cull) split(items, 0, n, (size_t)kClusterTris * kSuperClusters, boxes, sup_ranges);
-        else sup_ranges.emplace_back(0, n);
+        else for (size_t s0 = 0; s0 < n; s0 += (size_t)kClusterTris * kSuperClusters) sup_ranges.emplace_back(s0, std::min<size_t>(n, s0 + kClusterTris * kSuperClusters));   // list order
         for (auto [sb, se] : sup_ranges) {
             std::vector<std::pair<size_t, size_t>> cl_ranges;
             if (enable_cull) split(items, sb, se, kClusterTris, boxes, cl_ranges);
-            else cl_ranges.emplace_back(sb, se);
+            else for (size_t c0 = sb; c0 < se; c0 += kClusterTris) cl_ranges.emplace_back(c0, std::min<size_t>(se, c0 + kClusterTris));
             DevSuper S{};
-            S.cl_begin = (uint32_t)out.clusters.size(); S.cl_count = (uint32_t)cl_ranges.size();
+            S.tri_begin = (uint32_t)out.slot_tri.size();                     // a multiple of 8 by construction
+            S.tri_count = (uint32_t)(se - sb);
             for (int k = 0; k < 3; k++) { S.lo[k] = FLT_MAX; S.hi[k] = -FLT_MAX; }
-            for (auto [cb, ce] : cl_ranges) {
+            for (size_t ci = 0; ci < cl_ranges.size(); ci++) {
+                auto [cb, ce] = cl_ranges[ci];
+                // every cluster but the last of a super-cluster must be full, so that cluster c starts at slot tri_begin + 8c
+                if (ci + 1 < cl_ranges.size() && ce - cb != kClusterTris) throw Error{RRT_ERR_INVALID_ARG, "internal: cluster split is not 8-aligned"};
                 std::sort(items.begin() + cb, items.begin() + ce);          // list order inside a cluster
-                DevCluster C{};
-                C.tri_begin = (uint32_t)out.slot_tri.size(); C.tri_count = (uint32_t)(ce - cb);
+                DevClusterBox C{};
                 double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
                 for (size_t i = cb; i < ce; i++) {
                     const uint32_t it = items[i];
@@ -107,12 +110,14 @@ void build_clusters(const Model& m, bool enable_cull, ClusterSet& out) {
                     C.hi[k] = enable_cull ? round_up(hi[k] + pad) : FLT_MAX;
                     S.lo[k] = std::min(S.lo[k], C.lo[k]); S.hi[k] = std::max(S.hi[k], C.hi[k]);
                 }
-                out.clusters.push_back(C);
+                out.cboxes.push_back(C);
             }
+            while (out.slot_tri.size() % kClusterTris) { out.slot_tri.push_back(kPadSlot); out.slot_pos.push_back(0); }   // pad to the next cluster boundary
             out.supers.push_back(S);
         }
         out.node_sup_count[node] = (uint32_t)out.supers.size() - out.node_sup_begin[node];
     }
+    for (int i = 0; i < 8; i++) out.cboxes.push_back(DevClusterBox{});   // spare records: the kernel always loads 8 boxes per super-cluster
 }
 
 }  // namespace rrt

@@ -13,22 +13,27 @@
 
 namespace rrt {
 
-struct DevNode {                 // 64 B
+struct DevNode {                 // 96 B
     double lo[3], hi[3];         // Aabb, aabb.rs:4-8
+    double mid[3];               // the split planes lo + (hi-lo)/2 (octree.rs:136-138): with lo/hi they ARE the 8 children's boxes
     uint32_t first_child;        // 0 = leaf; children are first_child..first_child+7 (octree.rs:226-238)
     uint32_t sup_begin;          // first super-cluster of this node's own triangle list (clusters.cpp)
     uint32_t sup_count;
     uint32_t flags;              // bit k (0..7): child k has triangle_count > 0; bit 8: this node has triangle_count > 0 (ray.rs:112)
+    uint32_t s0_begin, s0_count; // slot range of the first super-cluster (the only one when sup_count == 1)
 };
-static_assert(sizeof(DevNode) == 64, "DevNode must be 64 bytes");
+static_assert(sizeof(DevNode) == 96, "DevNode must be 96 bytes");
 
 struct DevTriGeom { double v1[3], e1[3], e2[3]; uint32_t pos, _pad; };   // 80 B; pos = position in the node's own list (tie-break, ray.rs:124)
 static_assert(sizeof(DevTriGeom) == 80, "DevTriGeom must be 80 bytes");
 
 // own-list index (clusters.cpp): padded f32 boxes, rounded outward
-struct DevCluster { float lo[3], hi[3]; uint32_t tri_begin, tri_count; };   // 32 B: a run of <= 8 slots
-struct DevSuper { float lo[3], hi[3]; uint32_t cl_begin, cl_count; };       // 32 B: a run of <= 8 clusters
-static_assert(sizeof(DevCluster) == 32 && sizeof(DevSuper) == 32, "cluster records must be 32 bytes");
+// A super-cluster owns the slots [tri_begin, tri_begin + tri_count), tri_begin a multiple of 8, tri_count <= 64; its cluster c is the
+// 8 slots from tri_begin + 8c, and the box of the cluster that starts at slot s is cboxes[s / 8].  Slots between the end of a
+// super-cluster and the next multiple of 8 are padding (all-zero geometry, never hit).
+struct DevSuper { float lo[3], hi[3]; uint32_t tri_begin, tri_count; };     // 32 B
+struct DevClusterBox { float lo[3], hi[3]; uint32_t _pad[2]; };             // 32 B
+static_assert(sizeof(DevClusterBox) == 32 && sizeof(DevSuper) == 32, "cluster records must be 32 bytes");
 
 struct DevTriAttr {                                                // 128 B: one cache line per shaded hit
     double uv[6];                // t1.x,t1.y, t2.x,t2.y, t3.x,t3.y (raytracer.rs:45-50 read x,y only)
@@ -48,7 +53,7 @@ struct DevScene {                // passed to kernels by value (kernarg segment 
     const DevNode* nodes;
     const DevTriGeom* geom;
     const DevSuper* supers;
-    const DevCluster* clusters;
+    const DevClusterBox* cboxes;
     const DevTriAttr* attr;
     const DevMaterial* mats;
     const DevTexture* tex;
@@ -87,11 +92,12 @@ namespace rrt {
 struct Model;
 struct ClusterSet {
     std::vector<DevSuper> supers;
-    std::vector<DevCluster> clusters;
-    std::vector<uint32_t> slot_tri, slot_pos;          // per device slot: triangle index in push order, position in its node's own list
+    std::vector<DevClusterBox> cboxes;                 // one per 8 slots, + 8 spare records so a 4x64-byte burst never leaves the buffer
+    std::vector<uint32_t> slot_tri, slot_pos;          // per device slot: triangle index in push order (kPadSlot for padding), position in its node's own list
     std::vector<uint32_t> node_sup_begin, node_sup_count;
     double scene_magnitude = 0;
 };
+constexpr uint32_t kPadSlot = 0xFFFFFFFFu;
 void build_clusters(const Model& m, bool enable_cull, ClusterSet& out);
 
 }  // namespace rrt

@@ -63,18 +63,45 @@ struct Stack {
     __device__ __forceinline__ uint32_t& fc(uint32_t l) const { return *reinterpret_cast<uint32_t*>(base + l * kLevelBytes + 1024 + lane * 4); }
 };
 
-// ------------------------------------------------------------------------------------------------ primitives
-// One triangle held in SGPRs (wave-uniform): v1 and the two precomputed edges.
+// ------------------------------------------------------------------------------------------------ wave-uniform record loads
+// Every record below is fetched with ONE scalar load burst of its full size (s_load_dwordx8/x16) so that a record costs one memory
+// round trip; letting the compiler load fields one by one split a 32-byte record into three dependent round trips.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ double mkd(uint32_t lo, uint32_t hi) { return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo); }
+__device__ __forceinline__ float mkf(uint32_t x) { return __builtin_bit_cast(float, x); }
+
+struct UNode { double lo[3], hi[3], mid[3]; uint32_t first_child, sup_begin, sup_count, flags, s0_begin, s0_count; };
+__device__ __forceinline__ UNode load_unode(const RRT_CONSTANT DevNode* p) {
+    const u32x16 a = *(const RRT_CONSTANT u32x16*)p;
+    const u32x8 b = *(const RRT_CONSTANT u32x8*)((const RRT_CONSTANT char*)p + 64);
+    UNode n;
+    n.lo[0] = mkd(a[0], a[1]); n.lo[1] = mkd(a[2], a[3]); n.lo[2] = mkd(a[4], a[5]);
+    n.hi[0] = mkd(a[6], a[7]); n.hi[1] = mkd(a[8], a[9]); n.hi[2] = mkd(a[10], a[11]);
+    n.mid[0] = mkd(a[12], a[13]); n.mid[1] = mkd(a[14], a[15]); n.mid[2] = mkd(b[0], b[1]);
+    n.first_child = b[2]; n.sup_begin = b[3]; n.sup_count = b[4]; n.flags = b[5]; n.s0_begin = b[6]; n.s0_count = b[7];
+    return n;
+}
+
+struct UBox { float lox, loy, loz, hix, hiy, hiz; uint32_t a, b; };   // DevSuper (a = tri_begin, b = tri_count) or DevClusterBox
+__device__ __forceinline__ UBox mk_ubox(u32x8 r) { UBox x; x.lox = mkf(r[0]); x.loy = mkf(r[1]); x.loz = mkf(r[2]); x.hix = mkf(r[3]); x.hiy = mkf(r[4]); x.hiz = mkf(r[5]); x.a = r[6]; x.b = r[7]; return x; }
+__device__ __forceinline__ UBox load_ubox(const RRT_CONSTANT void* p) { return mk_ubox(*(const RRT_CONSTANT u32x8*)p); }
+
+// One triangle held in SGPRs (wave-uniform): v1 and the two precomputed edges, plus its position in the node's own list.
 struct UTri { double v1x, v1y, v1z, e1x, e1y, e1z, e2x, e2y, e2z; uint32_t pos; };
 __device__ __forceinline__ UTri load_utri(const RRT_CONSTANT DevTriGeom* g) {
+    const u32x16 a = *(const RRT_CONSTANT u32x16*)g;
+    const u32x4 b = *(const RRT_CONSTANT u32x4*)((const RRT_CONSTANT char*)g + 64);
     UTri t;
-    t.v1x = g->v1[0]; t.v1y = g->v1[1]; t.v1z = g->v1[2];
-    t.e1x = g->e1[0]; t.e1y = g->e1[1]; t.e1z = g->e1[2];
-    t.e2x = g->e2[0]; t.e2y = g->e2[1]; t.e2z = g->e2[2];
-    t.pos = g->pos;
+    t.v1x = mkd(a[0], a[1]); t.v1y = mkd(a[2], a[3]); t.v1z = mkd(a[4], a[5]);
+    t.e1x = mkd(a[6], a[7]); t.e1y = mkd(a[8], a[9]); t.e1z = mkd(a[10], a[11]);
+    t.e2x = mkd(a[12], a[13]); t.e2y = mkd(a[14], a[15]); t.e2z = mkd(b[0], b[1]);
+    t.pos = b[2];
     return t;
 }
 
+// ------------------------------------------------------------------------------------------------ primitives
 // Ray::intersect_with_triangle, ray.rs:56-94, against a wave-uniform triangle (SGPR operands).  Returns t only; the
 // winning triangle's (u,v) are recomputed once per hit by mt_full (same arithmetic => same bits).
 //
@@ -89,6 +116,7 @@ __device__ __forceinline__ UTri load_utri(const RRT_CONSTANT DevTriGeom* g) {
 //   (F4) sign(eq) != sign(a)                                  =>  t <= 0, so `t > eps` fails.
 // Whatever the filters let through takes the reference's exact path (divide included), so borderline cases are decided by
 // the reference's own arithmetic.  NaNs fail every filter comparison and fall through to the exact path.
+// A padding slot (all-zero record, clusters.cpp) has a = 0 and is rejected as parallel (ray.rs:66).
 constexpr double kC40 = 1.0 + 0x1p-40, kC30 = 1.0 + 0x1p-30;
 __device__ __forceinline__ bool mt_uniform(const UTri& g, V3 o, V3 d, double& t_out) {
     const double hx = d.y * g.e2z - d.z * g.e2y;
@@ -140,11 +168,9 @@ __device__ __forceinline__ bool mt_full(const DevTriGeom* g, V3 o, V3 d, double&
     return t > kEps;
 }
 
-// Ray::intersect_aabb, ray.rs:21-54, against a wave-uniform box.  fmin/fmax == Rust f64::min/max (NaN-ignoring).
-__device__ __forceinline__ bool slab_uniform(const RRT_CONSTANT DevNode* b, V3 o, V3 d, double& t_out) {
-    const double t1 = (b->lo[0] - o.x) / d.x, t2 = (b->hi[0] - o.x) / d.x;
-    const double t3 = (b->lo[1] - o.y) / d.y, t4 = (b->hi[1] - o.y) / d.y;
-    const double t5 = (b->lo[2] - o.z) / d.z, t6 = (b->hi[2] - o.z) / d.z;
+// Ray::intersect_aabb, ray.rs:21-54, on one child box given the six quotients t1..t6 = (bound - o)/d of its planes (ray.rs:22-27).
+// fmin/fmax == Rust f64::min/max (NaN-ignoring).
+__device__ __forceinline__ bool slab_from_quotients(double t1, double t2, double t3, double t4, double t5, double t6, double& t_out) {
     const double tmin = fmax(fmax(fmin(t1, t2), fmin(t3, t4)), fmin(t5, t6));
     const double tmax = fmin(fmin(fmax(t1, t2), fmax(t3, t4)), fmax(t5, t6));
     if (tmax < 0.0) return false;        // ray.rs:39-41
@@ -168,11 +194,11 @@ __device__ __forceinline__ Ray32 make_ray32(V3 o, V3 d, float limit, bool enable
     r.nx = -ox * r.ix; r.ny = -oy * r.iy; r.nz = -oz * r.iz;
     return r;
 }
-// true unless the ray (t >= 0) certainly misses the padded box; lo/hi are wave-uniform
-__device__ __forceinline__ bool slab32(const float lox, const float loy, const float loz, const float hix, const float hiy, const float hiz, const Ray32& r) {
-    const float ax = __builtin_fmaf(lox, r.ix, r.nx), bx = __builtin_fmaf(hix, r.ix, r.nx);
-    const float ay = __builtin_fmaf(loy, r.iy, r.ny), by = __builtin_fmaf(hiy, r.iy, r.ny);
-    const float az = __builtin_fmaf(loz, r.iz, r.nz), bz = __builtin_fmaf(hiz, r.iz, r.nz);
+// true unless the ray (t >= 0) certainly misses the padded box; the box is wave-uniform
+__device__ __forceinline__ bool slab32(const UBox& b, const Ray32& r) {
+    const float ax = __builtin_fmaf(b.lox, r.ix, r.nx), bx = __builtin_fmaf(b.hix, r.ix, r.nx);
+    const float ay = __builtin_fmaf(b.loy, r.iy, r.ny), by = __builtin_fmaf(b.hiy, r.iy, r.ny);
+    const float az = __builtin_fmaf(b.loz, r.iz, r.nz), bz = __builtin_fmaf(b.hiz, r.iz, r.nz);
     const float tmin = fmaxf(fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)), 0.0f);
     const float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
     return r.nocull || tmin <= tmax;
@@ -194,7 +220,8 @@ struct Prof { unsigned long long c[16]; };
 // Ray::intersect_with_octant_with_max_t(octree, 0, max_t), ray.rs:104-168, for all 64 lanes at once.
 // Must be called from wave-uniform control flow; lanes with active == false take no part.
 // Result: slot == kNone <=> None; otherwise (t, slot) of the returned triangle.
-__device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stack& stk, bool active, V3 o, V3 d, double max_t,
+// any_ok: the caller only uses Some/None of the result (shadow query, raytracer.rs:181-187).
+__device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stack& stk, bool active, bool any_ok, V3 o, V3 d, double max_t,
                                          double& out_t, uint32_t& out_slot) {
     bool done = !active;
     uint32_t cur = 0;        // node this lane has to enter next
@@ -203,79 +230,132 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
     const RRT_CONSTANT DevNode* nodes = (const RRT_CONSTANT DevNode*)S.nodes;
     const RRT_CONSTANT DevTriGeom* geom = (const RRT_CONSTANT DevTriGeom*)S.geom;
     const RRT_CONSTANT DevSuper* supers = (const RRT_CONSTANT DevSuper*)S.supers;
-    const RRT_CONSTANT DevCluster* clusters = (const RRT_CONSTANT DevCluster*)S.clusters;
+    const RRT_CONSTANT DevClusterBox* cboxes = (const RRT_CONSTANT DevClusterBox*)S.cboxes;
     const Ray32 r32 = make_ray32(o, d, S.cull_limit, S.cull_enabled != 0);
 
     PROF_ADD(6, 1); PROF_ADD(7, __popcll(__ballot(active)));
     for (;;) {
         const unsigned long long pending = __ballot(!done);
         if (pending == 0) break;
-        PROF_ADD(0, 1); PROF_ADD(1, __popcll(__ballot(!done && cur == (uint32_t)__builtin_amdgcn_readlane(cur, __builtin_ctzll(pending)))));
         const int leader = __builtin_ctzll(pending);
         const uint32_t unode = __builtin_amdgcn_readlane(cur, leader);   // wave-uniform node id
-        const RRT_CONSTANT DevNode* N = nodes + unode;
-        const uint32_t fc = N->first_child, sb = N->sup_begin, sc = N->sup_count, fl = N->flags;
+        const UNode N = load_unode(nodes + unode);
+        const uint32_t fc = N.first_child, sb = N.sup_begin, sc = N.sup_count, fl = N.flags;
+        PROF_ADD(0, 1); PROF_ADD(1, __popcll(__ballot(!done && cur == unode)));
         if (!done && cur == unode) {
             bool returning;
             if (!(fl & 0x100u)) {                                        // triangle_count == 0 -> None, ray.rs:112-114
                 returning = true; ret_slot = kNone; ret_t = kInf;
             } else {
-                double own_t = (sp == 0) ? max_t : kInf;                 // ray.rs:117 (children are entered with +inf, ray.rs:96-102,153)
-                uint32_t own_slot = kNone;
-                uint32_t own_pos = 0;
-                // ray.rs:119-129 as an arg-min over the list: super-cluster boxes -> cluster boxes -> triangles.  A later list position never
-                // replaces an equal t (strict < in the reference keeps the first), so ties go to the smaller `pos`.
-                for (uint32_t si = 0; si < sc; ++si) {
-                    const RRT_CONSTANT DevSuper* SP = supers + sb + si;
-                    const uint32_t cb = SP->cl_begin, cc = SP->cl_count;
-                    const bool hs = slab32(SP->lo[0], SP->lo[1], SP->lo[2], SP->hi[0], SP->hi[1], SP->hi[2], r32);
-                    PROF_ADD(10, 1);
-                    if (__ballot(hs) == 0) continue;
-                    for (uint32_t ci = 0; ci < cc; ++ci) {
-                        const RRT_CONSTANT DevCluster* CP = clusters + cb + ci;
-                        const uint32_t tb = CP->tri_begin, tc = CP->tri_count;
-                        const bool hc = hs && slab32(CP->lo[0], CP->lo[1], CP->lo[2], CP->hi[0], CP->hi[1], CP->hi[2], r32);
-                        PROF_ADD(11, 1);
-                        if (__ballot(hc) == 0) continue;
-                        UTri cur = load_utri(geom + tb);
-                        for (uint32_t s = 0; s < tc; ++s) {
-                            const UTri nxt = load_utri(geom + tb + ((s + 1 < tc) ? s + 1 : s));   // scalar prefetch of the next triangle
-                            double t;
-                            PROF_ADD(2, 1); PROF_ADD(3, __popcll(__ballot(hc)));
-                            if (hc && mt_uniform(cur, o, d, t) && (t < own_t || (t == own_t && cur.pos < own_pos))) { own_t = t; own_slot = tb + s; own_pos = cur.pos; }
-                            cur = nxt;
-                        }
-                    }
-                }
-                if (fc == 0) {                                           // leaf: no children -> returns its own result (ray.rs:163-167 with child_dist = inf)
-                    returning = true; ret_slot = own_slot; ret_t = own_t;
-                } else {
-                    // children: slab test in child order (ray.rs:135-144).  Children whose triangle_count is 0 return None at
-                    // once (ray.rs:112) and dropping entries does not disturb a stable sort, so they are skipped untested.
+                // ---- children first (their boxes are this node's lo/mid/hi, which can then leave the SGPRs): slab test in child order
+                // (ray.rs:135-144).  Children whose triangle_count is 0 return None at once (ray.rs:112) and dropping entries does not disturb a
+                // stable sort, so they are skipped untested.
+                uint32_t order = 0, nchild = 0;
+                if (fc != 0) {
+                    PROF_ADD(12, 1);
+                    // The eight children are cut from this node's box by its three mid planes (octree.rs:136-225), so their 48 slab bounds are
+                    // only nine distinct planes {lo, mid, hi} x {x, y, z}, all in the node record: the reference's quotient (bound - o)/d
+                    // (ray.rs:22-27) is formed ONCE per plane that some non-empty child uses (6..9 IEEE divides per node instead of 6 per
+                    // child), with the reference's operands, and each child's test is then the reference's min/max on those quotients.
+                    // child k = BBL,BFL,BFR,BBR,TBL,TFL,TFR,TBR (octree.rs:216-225): upper x half for k in {2,3,6,7}, y {4..7}, z {1,2,5,6}
+                    double qlx = 0, qmx = 0, qhx = 0, qly = 0, qmy = 0, qhy = 0, qlz = 0, qmz = 0, qhz = 0;
+                    if (fl & 0xFFu) { qmx = (N.mid[0] - o.x) / d.x; qmy = (N.mid[1] - o.y) / d.y; qmz = (N.mid[2] - o.z) / d.z; }
+                    if (fl & 0x33u) qlx = (N.lo[0] - o.x) / d.x;
+                    if (fl & 0xCCu) qhx = (N.hi[0] - o.x) / d.x;
+                    if (fl & 0x0Fu) qly = (N.lo[1] - o.y) / d.y;
+                    if (fl & 0xF0u) qhy = (N.hi[1] - o.y) / d.y;
+                    if (fl & 0x99u) qlz = (N.lo[2] - o.z) / d.z;
+                    if (fl & 0x66u) qhz = (N.hi[2] - o.z) / d.z;
                     double tk[8]; bool vk[8];
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         vk[k] = false; tk[k] = kInf;
                         if (fl & (1u << k)) {
-                            double t;
+                            constexpr int hx[8] = {0, 0, 1, 1, 0, 0, 1, 1}, hy[8] = {0, 0, 0, 0, 1, 1, 1, 1}, hz[8] = {0, 1, 1, 0, 0, 1, 1, 0};
+                            double t = kInf;
                             PROF_ADD(8, 1); PROF_ADD(9, __popcll(__ballot(1)));
-                            if (slab_uniform(nodes + fc + k, o, d, t)) { vk[k] = true; tk[k] = (t != t) ? kInf : t; }   // NaN sorts last (reference panics, ray.rs:147)
+                            if (slab_from_quotients(hx[k] ? qmx : qlx, hx[k] ? qhx : qmx, hy[k] ? qmy : qly, hy[k] ? qhy : qmy, hz[k] ? qmz : qlz, hz[k] ? qhz : qmz, t)) {
+                                vk[k] = true; tk[k] = (t != t) ? kInf : t;                                              // NaN sorts last (reference panics, ray.rs:147)
+                            }
                         }
                     }
-                    // stable ascending sort by t (ray.rs:146-147) as a rank computation
-                    uint32_t order = 0, n = 0;
+                    // stable ascending sort by t (ray.rs:146-147) as a rank computation over the non-empty children only
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
+                        if (!(fl & (1u << k))) continue;
                         uint32_t rank = 0;
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
-                            if (j == k) continue;
+                            if (j == k || !(fl & (1u << j))) continue;
                             const bool before = (j < k) ? (tk[j] <= tk[k]) : (tk[j] < tk[k]);
                             rank += (vk[j] && before) ? 1u : 0u;
                         }
-                        if (vk[k]) { order |= (uint32_t)k << (3u * rank); n++; }
+                        if (vk[k]) { order |= (uint32_t)k << (3u * rank); nchild++; }
                     }
-                    stk.own_t(sp) = own_t; stk.own_slot(sp) = own_slot; stk.meta(sp) = order | (n << 24); stk.fc(sp) = fc;
+                }
+                // ---- own list: ray.rs:119-129 as an arg-min over the list: super-cluster box -> its <= 8 cluster boxes -> triangles.
+                // A later list position never replaces an equal t (strict < in the reference keeps the first), so ties go to the smaller `pos`.
+                double own_t = (sp == 0) ? max_t : kInf;                 // ray.rs:117 (children are entered with +inf, ray.rs:96-102,153)
+                uint32_t own_slot = kNone;
+                uint32_t own_pos = 0;
+                if (sc) {
+                    // a node with a single super-cluster carries its slot range in the node record and skips the super-cluster box
+                    UBox SP; SP.a = N.s0_begin; SP.b = N.s0_count; SP.lox = SP.loy = SP.loz = SP.hix = SP.hiy = SP.hiz = 0.0f;
+                    if (sc > 1) SP = load_ubox(supers + sb);
+                    for (uint32_t si = 0; si < sc; ++si) {
+                        UBox SN = SP;
+                        if (si + 1 < sc) SN = load_ubox(supers + sb + si + 1);                            // scalar prefetch of the next super-cluster
+                        const bool hs = (sc == 1) || slab32(SP, r32);
+                        const uint32_t tb = SP.a, tn = SP.b;
+                        PROF_ADD(10, 1);
+                        if (__ballot(hs) != 0) {
+                            // the (up to) 8 cluster boxes of this super-cluster in bursts of 4; cluster c covers slots tb+8c .. tb+8c+7
+                            const RRT_CONSTANT u32x16* cb = (const RRT_CONSTANT u32x16*)(cboxes + (tb >> 3));
+                            const uint32_t nc = (tn + 7u) >> 3;
+                            uint32_t lane_hits = 0, wave_hits = 0;
+#define RRT_CL(c, v, off)                                                                                                          \
+                            if (c < nc) {                                                                                          \
+                                UBox B; B.lox = mkf(v[off]); B.loy = mkf(v[off + 1]); B.loz = mkf(v[off + 2]);                     \
+                                B.hix = mkf(v[off + 3]); B.hiy = mkf(v[off + 4]); B.hiz = mkf(v[off + 5]); B.a = 0; B.b = 0;       \
+                                const bool h = hs && slab32(B, r32);                                                              \
+                                PROF_ADD(11, 1);                                                                                   \
+                                lane_hits |= h ? (1u << c) : 0u;                                                                   \
+                                wave_hits |= (__ballot(h) != 0) ? (1u << c) : 0u;                                                  \
+                            }
+                            {
+                                const u32x16 c01 = cb[0], c23 = cb[1];
+                                RRT_CL(0u, c01, 0) RRT_CL(1u, c01, 8) RRT_CL(2u, c23, 0) RRT_CL(3u, c23, 8)
+                            }
+                            if (nc > 4u) {
+                                const u32x16 c45 = cb[2], c67 = cb[3];
+                                RRT_CL(4u, c45, 0) RRT_CL(5u, c45, 8) RRT_CL(6u, c67, 0) RRT_CL(7u, c67, 8)
+                            }
+#undef RRT_CL
+                            while (wave_hits) {
+                                const uint32_t c = __builtin_ctz(wave_hits);
+                                wave_hits &= wave_hits - 1u;
+                                const bool hc = (lane_hits >> c) & 1u;
+                                const uint32_t cb0 = tb + 8u * c, cn = (tn - 8u * c < 8u) ? tn - 8u * c : 8u;
+                                UTri tri = load_utri(geom + cb0);
+                                for (uint32_t s = 0; s < cn; ++s) {
+                                    UTri nxt = tri;
+                                    if (s + 1 < cn) nxt = load_utri(geom + cb0 + s + 1);                   // scalar prefetch of the next triangle
+                                    double t;
+                                    PROF_ADD(2, 1); PROF_ADD(3, __popcll(__ballot(hc)));
+                                    if (hc && mt_uniform(tri, o, d, t) && (t < own_t || (t == own_t && tri.pos < own_pos))) { own_t = t; own_slot = cb0 + s; own_pos = tri.pos; }
+                                    tri = nxt;
+                                }
+                            }
+                        }
+                        SP = SN;
+                    }
+                }
+                // A shadow query at the root that already holds an own hit (t < max_t) returns Some whatever the children do
+                // (ray.rs:163-167 picks child or own, both Some), and only Some/None is used (raytracer.rs:183-187): stop here.
+                if (fc == 0 || (any_ok && sp == 0 && own_slot != kNone)) {   // leaf: no children -> returns its own result (ray.rs:163-167 with child_dist = inf)
+                    returning = true; ret_slot = own_slot; ret_t = own_t;
+                } else {
+                    stk.own_t(sp) = own_t; stk.own_slot(sp) = own_slot; stk.meta(sp) = order | (nchild << 24); stk.fc(sp) = fc;
                     sp++;
                     returning = false;
                 }
@@ -346,13 +426,14 @@ __device__ __forceinline__ uint32_t trace_colour(PROF_DECL const DevScene& S, co
 
     while (__any(live)) {
         double t; uint32_t slot;
-        traverse(PROF_ARG S, stk, live, ro, rd, rmax, t, slot);
+        traverse(PROF_ARG S, stk, live, in_shadow, ro, rd, rmax, t, slot);
         if (live) {
             const bool found = slot != kNone;
             if (!in_shadow) {
                 if (!found) {
                     term = 0x00FFFFFFu; live = false;                                    // WHITE, raytracer.rs:109-111
                 } else {
+                    PROF_ADD(13, 1);
                     // --- hit: raytracer.rs:39-57
                     double u = 0, v = 0, t2;
                     mt_full(S.geom + slot, ro, rd, t2, u, v);
@@ -536,7 +617,7 @@ __global__ __launch_bounds__(64) void intersect_kernel(const DevScene S, uint32_
 #ifdef RRT_PROFILE
     Prof prof{};
 #endif
-    traverse(PROF_ARG S, stk, ok, o, d, mt, t, slot);
+    traverse(PROF_ARG S, stk, ok, false, o, d, mt, t, slot);
     if (!ok) return;
     if (slot == kNone) { hit[i] = 0; t_out[i] = 0; u_out[i] = 0; v_out[i] = 0; tri_out[i] = kNone; return; }
     double t2, u = 0, v = 0;
