@@ -118,6 +118,30 @@ void build_clusters(const Model& m, bool enable_cull, ClusterSet& out) {
         out.node_sup_count[node] = (uint32_t)out.supers.size() - out.node_sup_begin[node];
     }
     for (int i = 0; i < 8; i++) out.cboxes.push_back(DevClusterBox{});   // spare records: the kernel always loads 8 boxes per super-cluster
+
+    // ---- tight bounds of every subtree (all triangles counted by triangle_count, octree.rs:75), as padded f32 boxes grouped by sibling set.
+    // A child whose subtree the ray cannot reach returns None (ray.rs:112-167 finds no triangle), exactly like an empty child, so the walk may
+    // drop it from the candidate list before the exact slab test; children always have larger ids than their parent, so one reverse sweep
+    // accumulates the bounds bottom-up.
+    std::vector<double> slo(3 * n_nodes, DBL_MAX), shi(3 * n_nodes, -DBL_MAX);
+    for (size_t node = n_nodes; node-- > 0;) {
+        for (uint32_t i = T.own_off[node]; i < T.own_off[node + 1]; i++) {
+            const TriBox tb = tri_box(m.triangles[T.own_idx[i]]);
+            for (int k = 0; k < 3; k++) { slo[3 * node + k] = std::min(slo[3 * node + k], tb.lo[k]); shi[3 * node + k] = std::max(shi[3 * node + k], tb.hi[k]); }
+        }
+        if (T.first_child[node]) for (uint32_t c = T.first_child[node]; c < T.first_child[node] + 8; c++)
+            for (int k = 0; k < 3; k++) { slo[3 * node + k] = std::min(slo[3 * node + k], slo[3 * c + k]); shi[3 * node + k] = std::max(shi[3 * node + k], shi[3 * c + k]); }
+    }
+    out.child_boxes.assign(n_nodes > 1 ? n_nodes - 1 : 0, DevClusterBox{});           // node id c >= 1 -> child_boxes[c - 1]; siblings are 8 consecutive records
+    for (size_t c = 1; c < n_nodes; c++) {
+        DevClusterBox& B = out.child_boxes[c - 1];
+        const bool empty = T.tri_count[c] == 0 || slo[3 * c] > shi[3 * c];
+        for (int k = 0; k < 3; k++) {
+            B.lo[k] = !enable_cull ? -FLT_MAX : empty ? FLT_MAX : round_down(slo[3 * c + k] - pad);
+            B.hi[k] = !enable_cull ? FLT_MAX : empty ? -FLT_MAX : round_up(shi[3 * c + k] + pad);
+        }
+    }
+    for (int i = 0; i < 8; i++) out.child_boxes.push_back(DevClusterBox{});
 }
 
 }  // namespace rrt

@@ -231,6 +231,7 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
     const RRT_CONSTANT DevTriGeom* geom = (const RRT_CONSTANT DevTriGeom*)S.geom;
     const RRT_CONSTANT DevSuper* supers = (const RRT_CONSTANT DevSuper*)S.supers;
     const RRT_CONSTANT DevClusterBox* cboxes = (const RRT_CONSTANT DevClusterBox*)S.cboxes;
+    const RRT_CONSTANT DevClusterBox* child_boxes = (const RRT_CONSTANT DevClusterBox*)S.child_boxes;
     const Ray32 r32 = make_ray32(o, d, S.cull_limit, S.cull_enabled != 0);
 
     PROF_ADD(6, 1); PROF_ADD(7, __popcll(__ballot(active)));
@@ -253,28 +254,46 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                 uint32_t order = 0, nchild = 0;
                 if (fc != 0) {
                     PROF_ADD(12, 1);
-                    // The eight children are cut from this node's box by its three mid planes (octree.rs:136-225), so their 48 slab bounds are
+                    // (1) conservative fp32 filter against the TIGHT bounds of each non-empty child's subtree (clusters.cpp): a child the ray cannot
+                    // reach returns None like an empty one, so it is dropped here; `reach` = children some lane may still hit (wave-uniform).
+                    uint32_t lane_reach = 0, reach = 0;
+                    {
+                        const RRT_CONSTANT u32x16* cbx = (const RRT_CONSTANT u32x16*)(child_boxes + (fc - 1u));
+#define RRT_CB(k, v, off)                                                                                                          \
+                        if (fl & (1u << k)) {                                                                                      \
+                            UBox B; B.lox = mkf(v[off]); B.loy = mkf(v[off + 1]); B.loz = mkf(v[off + 2]);                         \
+                            B.hix = mkf(v[off + 3]); B.hiy = mkf(v[off + 4]); B.hiz = mkf(v[off + 5]); B.a = 0; B.b = 0;           \
+                            const bool h = slab32(B, r32);                                                                        \
+                            lane_reach |= h ? (1u << k) : 0u;                                                                      \
+                            reach |= (__ballot(h) != 0) ? (1u << k) : 0u;                                                          \
+                        }
+                        if (fl & 0x0Fu) { const u32x16 b01 = cbx[0], b23 = cbx[1]; RRT_CB(0, b01, 0) RRT_CB(1, b01, 8) RRT_CB(2, b23, 0) RRT_CB(3, b23, 8) }
+                        if (fl & 0xF0u) { const u32x16 b45 = cbx[2], b67 = cbx[3]; RRT_CB(4, b45, 0) RRT_CB(5, b45, 8) RRT_CB(6, b67, 0) RRT_CB(7, b67, 8) }
+#undef RRT_CB
+                    }
+                    // (2) The eight children are cut from this node's box by its three mid planes (octree.rs:136-225), so their 48 slab bounds are
                     // only nine distinct planes {lo, mid, hi} x {x, y, z}, all in the node record: the reference's quotient (bound - o)/d
-                    // (ray.rs:22-27) is formed ONCE per plane that some non-empty child uses (6..9 IEEE divides per node instead of 6 per
+                    // (ray.rs:22-27) is formed ONCE per plane that some reachable child uses (6..9 IEEE divides per node instead of 6 per
                     // child), with the reference's operands, and each child's test is then the reference's min/max on those quotients.
                     // child k = BBL,BFL,BFR,BBR,TBL,TFL,TFR,TBR (octree.rs:216-225): upper x half for k in {2,3,6,7}, y {4..7}, z {1,2,5,6}
                     double qlx = 0, qmx = 0, qhx = 0, qly = 0, qmy = 0, qhy = 0, qlz = 0, qmz = 0, qhz = 0;
-                    if (fl & 0xFFu) { qmx = (N.mid[0] - o.x) / d.x; qmy = (N.mid[1] - o.y) / d.y; qmz = (N.mid[2] - o.z) / d.z; }
-                    if (fl & 0x33u) qlx = (N.lo[0] - o.x) / d.x;
-                    if (fl & 0xCCu) qhx = (N.hi[0] - o.x) / d.x;
-                    if (fl & 0x0Fu) qly = (N.lo[1] - o.y) / d.y;
-                    if (fl & 0xF0u) qhy = (N.hi[1] - o.y) / d.y;
-                    if (fl & 0x99u) qlz = (N.lo[2] - o.z) / d.z;
-                    if (fl & 0x66u) qhz = (N.hi[2] - o.z) / d.z;
+                    if (reach & 0xFFu) { qmx = (N.mid[0] - o.x) / d.x; qmy = (N.mid[1] - o.y) / d.y; qmz = (N.mid[2] - o.z) / d.z; }
+                    if (reach & 0x33u) qlx = (N.lo[0] - o.x) / d.x;
+                    if (reach & 0xCCu) qhx = (N.hi[0] - o.x) / d.x;
+                    if (reach & 0x0Fu) qly = (N.lo[1] - o.y) / d.y;
+                    if (reach & 0xF0u) qhy = (N.hi[1] - o.y) / d.y;
+                    if (reach & 0x99u) qlz = (N.lo[2] - o.z) / d.z;
+                    if (reach & 0x66u) qhz = (N.hi[2] - o.z) / d.z;
                     double tk[8]; bool vk[8];
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         vk[k] = false; tk[k] = kInf;
-                        if (fl & (1u << k)) {
+                        if (reach & (1u << k)) {
                             constexpr int hx[8] = {0, 0, 1, 1, 0, 0, 1, 1}, hy[8] = {0, 0, 0, 0, 1, 1, 1, 1}, hz[8] = {0, 1, 1, 0, 0, 1, 1, 0};
                             double t = kInf;
                             PROF_ADD(8, 1); PROF_ADD(9, __popcll(__ballot(1)));
-                            if (slab_from_quotients(hx[k] ? qmx : qlx, hx[k] ? qhx : qmx, hy[k] ? qmy : qly, hy[k] ? qhy : qmy, hz[k] ? qmz : qlz, hz[k] ? qhz : qmz, t)) {
+                            if (((lane_reach >> k) & 1u) &&
+                                slab_from_quotients(hx[k] ? qmx : qlx, hx[k] ? qhx : qmx, hy[k] ? qmy : qly, hy[k] ? qhy : qmy, hz[k] ? qmz : qlz, hz[k] ? qhz : qmz, t)) {
                                 vk[k] = true; tk[k] = (t != t) ? kInf : t;                                              // NaN sorts last (reference panics, ray.rs:147)
                             }
                         }
@@ -282,11 +301,11 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                     // stable ascending sort by t (ray.rs:146-147) as a rank computation over the non-empty children only
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
-                        if (!(fl & (1u << k))) continue;
+                        if (!(reach & (1u << k))) continue;
                         uint32_t rank = 0;
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
-                            if (j == k || !(fl & (1u << j))) continue;
+                            if (j == k || !(reach & (1u << j))) continue;
                             const bool before = (j < k) ? (tk[j] <= tk[k]) : (tk[j] < tk[k]);
                             rank += (vk[j] && before) ? 1u : 0u;
                         }
