@@ -413,6 +413,11 @@ __device__ __forceinline__ uint64_t f64_as_usize(double x) {   // Rust `as usize
     if (x >= 18446744073709551616.0) return ~0ull;
     return (uint64_t)x;
 }
+__device__ __forceinline__ uint64_t umod(uint64_t x, uint32_t m) {   // x % m without the 64-bit software divide when it can be avoided
+    if ((m & (m - 1u)) == 0u) return x & (uint64_t)(m - 1u);        // power-of-two texture sizes
+    if (x <= 0xFFFFFFFFull) return (uint32_t)x % m;
+    return x % m;
+}
 __device__ __forceinline__ uint32_t clamp_u8(double x) {       // clamp(0.0, 255.0) as u8 (raytracer.rs:97-108)
     if (x < 0.0) x = 0.0;
     if (x > 255.0) x = 255.0;
@@ -465,8 +470,8 @@ __device__ __forceinline__ uint32_t trace_colour(PROF_DECL const DevScene& S, co
                     const double w = 1.0 - u - v;                                        // raytracer.rs:43
                     const double tex_x = A.uv[2] * u + A.uv[4] * v + A.uv[0] * w;        // raytracer.rs:45-47
                     const double tex_y = A.uv[3] * u + A.uv[5] * v + A.uv[1] * w;        // raytracer.rs:48-50
-                    const uint64_t txi = f64_as_usize(tex_x * (double)T.width) % T.width;    // raytracer.rs:52
-                    const uint64_t tyi = f64_as_usize(tex_y * (double)T.height) % T.height;  // raytracer.rs:53
+                    const uint64_t txi = umod(f64_as_usize(tex_x * (double)T.width), T.width);    // raytracer.rs:52
+                    const uint64_t tyi = umod(f64_as_usize(tex_y * (double)T.height), T.height);  // raytracer.rs:53
                     const uint8_t* tp = T.rgb + 3ull * ((uint64_t)T.width * tyi + txi);  // raytracer.rs:55
                     col = ((uint32_t)tp[0] << 16) | ((uint32_t)tp[1] << 8) | (uint32_t)tp[2];
                     // get_normal_at_intersection, raytracer.rs:114-162
