@@ -330,6 +330,7 @@ int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n
         S.supers = upload(rt.get(), CS.supers.data(), CS.supers.size());
         S.cboxes = upload(rt.get(), CS.cboxes.data(), CS.cboxes.size());
         S.child_boxes = upload(rt.get(), CS.child_boxes.data(), CS.child_boxes.size());
+        S.tboxes = upload(rt.get(), CS.tboxes.data(), CS.tboxes.size());
         S.cull_enabled = (o.flags & RRT_FLAG_NO_CULL) ? 0u : 1u;
         S.cull_limit = (float)(CS.scene_magnitude * 4.0);
         S.attr = upload(rt.get(), attr.data(), attr.size());

@@ -104,6 +104,12 @@ void build_clusters(const Model& m, bool enable_cull, ClusterSet& out) {
                     for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], boxes[it].lo[k]); hi[k] = std::max(hi[k], boxes[it].hi[k]); }
                     out.slot_tri.push_back(T.own_idx[b + it]);
                     out.slot_pos.push_back(it);                              // position in the node's `triangles` Vec (ray.rs:119)
+                    DevClusterBox TB{};
+                    for (int k = 0; k < 3; k++) {
+                        TB.lo[k] = enable_cull ? round_down(boxes[it].lo[k] - pad) : -FLT_MAX;
+                        TB.hi[k] = enable_cull ? round_up(boxes[it].hi[k] + pad) : FLT_MAX;
+                    }
+                    out.tboxes.push_back(TB);
                 }
                 for (int k = 0; k < 3; k++) {
                     C.lo[k] = enable_cull ? round_down(lo[k] - pad) : -FLT_MAX;
@@ -112,12 +118,17 @@ void build_clusters(const Model& m, bool enable_cull, ClusterSet& out) {
                 }
                 out.cboxes.push_back(C);
             }
-            while (out.slot_tri.size() % kClusterTris) { out.slot_tri.push_back(kPadSlot); out.slot_pos.push_back(0); }   // pad to the next cluster boundary
+            while (out.slot_tri.size() % kClusterTris) {                     // pad to the next cluster boundary; a padding slot's box is empty (never hit)
+                out.slot_tri.push_back(kPadSlot); out.slot_pos.push_back(0);
+                DevClusterBox TB{};
+                for (int k = 0; k < 3; k++) { TB.lo[k] = FLT_MAX; TB.hi[k] = -FLT_MAX; }
+                out.tboxes.push_back(TB);
+            }
             out.supers.push_back(S);
         }
         out.node_sup_count[node] = (uint32_t)out.supers.size() - out.node_sup_begin[node];
     }
-    for (int i = 0; i < 8; i++) out.cboxes.push_back(DevClusterBox{});   // spare records: the kernel always loads 8 boxes per super-cluster
+    for (int i = 0; i < 8; i++) { out.cboxes.push_back(DevClusterBox{}); out.tboxes.push_back(DevClusterBox{}); }   // spare records: box bursts never leave the buffers
 
     // ---- tight bounds of every subtree (all triangles counted by triangle_count, octree.rs:75), as padded f32 boxes grouped by sibling set.
     // A child whose subtree the ray cannot reach returns None (ray.rs:112-167 finds no triangle), exactly like an empty child, so the walk may

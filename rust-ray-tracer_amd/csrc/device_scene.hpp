@@ -55,6 +55,7 @@ struct DevScene {                // passed to kernels by value (kernarg segment 
     const DevSuper* supers;
     const DevClusterBox* cboxes;
     const DevClusterBox* child_boxes;
+    const DevClusterBox* tboxes;          // one padded box per slot (per triangle)
     const DevTriAttr* attr;
     const DevMaterial* mats;
     const DevTexture* tex;
@@ -93,6 +94,7 @@ namespace rrt {
 struct Model;
 struct ClusterSet {
     std::vector<DevSuper> supers;
+    std::vector<DevClusterBox> tboxes;                 // per slot, + 8 spare records
     std::vector<DevClusterBox> child_boxes;            // tight padded bounds of the subtree of node c at [c - 1]; the 8 children of a node are consecutive
     std::vector<DevClusterBox> cboxes;                 // one per 8 slots, + 8 spare records so a 4x64-byte burst never leaves the buffer
     std::vector<uint32_t> slot_tri, slot_pos;          // per device slot: triangle index in push order (kPadSlot for padding), position in its node's own list

@@ -232,6 +232,7 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
     const RRT_CONSTANT DevSuper* supers = (const RRT_CONSTANT DevSuper*)S.supers;
     const RRT_CONSTANT DevClusterBox* cboxes = (const RRT_CONSTANT DevClusterBox*)S.cboxes;
     const RRT_CONSTANT DevClusterBox* child_boxes = (const RRT_CONSTANT DevClusterBox*)S.child_boxes;
+    const RRT_CONSTANT DevClusterBox* tboxes = (const RRT_CONSTANT DevClusterBox*)S.tboxes;
     const Ray32 r32 = make_ray32(o, d, S.cull_limit, S.cull_enabled != 0);
 
     PROF_ADD(6, 1); PROF_ADD(7, __popcll(__ballot(active)));
@@ -355,14 +356,44 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                                 wave_hits &= wave_hits - 1u;
                                 const bool hc = (lane_hits >> c) & 1u;
                                 const uint32_t cb0 = tb + 8u * c, cn = (tn - 8u * c < 8u) ? tn - 8u * c : 8u;
-                                UTri tri = load_utri(geom + cb0);
-                                for (uint32_t s = 0; s < cn; ++s) {
-                                    UTri nxt = tri;
-                                    if (s + 1 < cn) nxt = load_utri(geom + cb0 + s + 1);                   // scalar prefetch of the next triangle
-                                    double t;
-                                    PROF_ADD(2, 1); PROF_ADD(3, __popcll(__ballot(hc)));
-                                    if (hc && mt_uniform(tri, o, d, t) && (t < own_t || (t == own_t && tri.pos < own_pos))) { own_t = t; own_slot = cb0 + s; own_pos = tri.pos; }
-                                    tri = nxt;
+                                // per-triangle boxes of this cluster (same conservative fp32 filter, one level down): only triangles whose box some
+                                // lane may hit are fetched (80-byte f64 records) and tested
+                                const RRT_CONSTANT u32x16* tbx = (const RRT_CONSTANT u32x16*)(tboxes + cb0);
+                                uint32_t lane_tri = 0, wave_tri = 0;
+#define RRT_TB(i, v, off)                                                                                                          \
+                                if (i < cn) {                                                                                      \
+                                    UBox B; B.lox = mkf(v[off]); B.loy = mkf(v[off + 1]); B.loz = mkf(v[off + 2]);                 \
+                                    B.hix = mkf(v[off + 3]); B.hiy = mkf(v[off + 4]); B.hiz = mkf(v[off + 5]); B.a = 0; B.b = 0;   \
+                                    const bool h = hc && slab32(B, r32);                                                          \
+                                    PROF_ADD(4, 1);                                                                                \
+                                    lane_tri |= h ? (1u << i) : 0u;                                                                \
+                                    wave_tri |= (__ballot(h) != 0) ? (1u << i) : 0u;                                               \
+                                }
+                                {
+                                    const u32x16 t01 = tbx[0], t23 = tbx[1];
+                                    RRT_TB(0u, t01, 0) RRT_TB(1u, t01, 8) RRT_TB(2u, t23, 0) RRT_TB(3u, t23, 8)
+                                }
+                                if (cn > 4u) {
+                                    const u32x16 t45 = tbx[2], t67 = tbx[3];
+                                    RRT_TB(4u, t45, 0) RRT_TB(5u, t45, 8) RRT_TB(6u, t67, 0) RRT_TB(7u, t67, 8)
+                                }
+#undef RRT_TB
+                                if (wave_tri) {
+                                    uint32_t s = __builtin_ctz(wave_tri);
+                                    wave_tri &= wave_tri - 1u;
+                                    UTri tri = load_utri(geom + cb0 + s);
+                                    for (;;) {
+                                        const uint32_t s_next = wave_tri ? (uint32_t)__builtin_ctz(wave_tri) : s;
+                                        UTri nxt = tri;
+                                        if (wave_tri) nxt = load_utri(geom + cb0 + s_next);                 // scalar prefetch of the next candidate triangle
+                                        double t;
+                                        const bool ht = (lane_tri >> s) & 1u;
+                                        PROF_ADD(2, 1); PROF_ADD(3, __popcll(__ballot(ht)));
+                                        if (ht && mt_uniform(tri, o, d, t) && (t < own_t || (t == own_t && tri.pos < own_pos))) { own_t = t; own_slot = cb0 + s; own_pos = tri.pos; }
+                                        if (!wave_tri) break;
+                                        wave_tri &= wave_tri - 1u;
+                                        tri = nxt; s = s_next;
+                                    }
                                 }
                             }
                         }
