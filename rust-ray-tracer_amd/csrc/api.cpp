@@ -337,7 +337,7 @@ int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n
         S.mats = upload(rt.get(), mats.data(), mats.size());
         S.tex = upload(rt.get(), texs.data(), texs.size());
         S.n_nodes = (uint32_t)n_nodes; S.n_slots = (uint32_t)n_slots; S.n_mats = (uint32_t)mats.size(); S.n_tex = (uint32_t)texs.size();
-        S.n_lights = n_lights; S.max_reflection_depth = o.max_reflection_depth; S.stack_levels = T.max_depth; S._pad = 0;
+        S.n_lights = n_lights; S.max_reflection_depth = o.max_reflection_depth; S.stack_levels = T.max_depth > 1 ? T.max_depth - 1 : 1;   // only internal nodes push a frame; the deepest level holds leaves S._pad = 0;
         S.origin[0] = origin.x; S.origin[1] = origin.y; S.origin[2] = origin.z;
         S.surface_offset = o.surface_offset;
         for (uint32_t i = 0; i < n_lights; i++) {

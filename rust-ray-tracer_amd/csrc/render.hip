@@ -53,14 +53,15 @@ __device__ __forceinline__ V3 cross(V3 a, V3 b) {                               
 __device__ __forceinline__ V3 normalised(V3 a) { return a / length(a); }                              // engine.rs:101-103
 
 // ------------------------------------------------------------------------------------------------ LDS stack
-// per wave: levels x 1280 B, level record = own_t[64] f64 | own_slot[64] u32 | meta[64] u32 | fc[64] u32
-constexpr uint32_t kLevelBytes = 64 * 8 + 3 * 64 * 4;
+// per wave: levels x 768 B, level record = own_slot[64] u32 | meta[64] u32 | fc[64] u32.  A frame does not keep the t of its own hit: the few
+// times an older frame's own hit is compared or returned, t is recomputed from the slot (t_of_slot: same arithmetic, same bits), which
+// keeps the stack at 12 bytes per lane and level so that LDS does not cap the number of resident waves.
+constexpr uint32_t kLevelBytes = 3 * 64 * 4;
 struct Stack {
     char* base; uint32_t lane;
-    __device__ __forceinline__ double& own_t(uint32_t l) const { return *reinterpret_cast<double*>(base + l * kLevelBytes + lane * 8); }
-    __device__ __forceinline__ uint32_t& own_slot(uint32_t l) const { return *reinterpret_cast<uint32_t*>(base + l * kLevelBytes + 512 + lane * 4); }
-    __device__ __forceinline__ uint32_t& meta(uint32_t l) const { return *reinterpret_cast<uint32_t*>(base + l * kLevelBytes + 768 + lane * 4); }
-    __device__ __forceinline__ uint32_t& fc(uint32_t l) const { return *reinterpret_cast<uint32_t*>(base + l * kLevelBytes + 1024 + lane * 4); }
+    __device__ __forceinline__ uint32_t& own_slot(uint32_t l) const { return *reinterpret_cast<uint32_t*>(base + l * kLevelBytes + lane * 4); }
+    __device__ __forceinline__ uint32_t& meta(uint32_t l) const { return *reinterpret_cast<uint32_t*>(base + l * kLevelBytes + 256 + lane * 4); }
+    __device__ __forceinline__ uint32_t& fc(uint32_t l) const { return *reinterpret_cast<uint32_t*>(base + l * kLevelBytes + 512 + lane * 4); }
 };
 
 // ------------------------------------------------------------------------------------------------ wave-uniform record loads
@@ -166,6 +167,15 @@ __device__ __forceinline__ bool mt_full(const DevTriGeom* g, V3 o, V3 d, double&
     const double t = f * dot(e2, q);
     t_out = t; u_out = u; v_out = v;
     return t > kEps;
+}
+
+// t of a triangle already known to be hit by this ray (the own hit of an older stack frame): ray.rs:60-87 again, same bits as the first time
+__device__ __forceinline__ double t_of_slot(const DevTriGeom* g, V3 o, V3 d) {
+    const V3 v1 = ld3(g->v1), e1 = ld3(g->e1), e2 = ld3(g->e2);
+    const V3 h = cross(d, e2);
+    const double f = 1.0 / dot(e1, h);
+    const V3 q = cross(o - v1, e1);
+    return f * dot(e2, q);
 }
 
 // Ray::intersect_aabb, ray.rs:21-54, on one child box given the six quotients t1..t6 = (bound - o)/d of its planes (ray.rs:22-27).
@@ -405,7 +415,7 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                 if (fc == 0 || (any_ok && sp == 0 && own_slot != kNone)) {   // leaf: no children -> returns its own result (ray.rs:163-167 with child_dist = inf)
                     returning = true; ret_slot = own_slot; ret_t = own_t;
                 } else {
-                    stk.own_t(sp) = own_t; stk.own_slot(sp) = own_slot; stk.meta(sp) = order | (nchild << 24); stk.fc(sp) = fc;
+                    stk.own_slot(sp) = own_slot; stk.meta(sp) = order | (nchild << 24); stk.fc(sp) = fc;
                     sp++;
                     returning = false;
                 }
@@ -420,14 +430,16 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                         cur = stk.fc(sp - 1) + ((m >> (3u * cursor)) & 7u);
                         break;
                     }
-                    ret_slot = stk.own_slot(sp - 1); ret_t = stk.own_t(sp - 1);   // no child hit: child_dist = inf -> own (ray.rs:163-167)
+                    ret_slot = stk.own_slot(sp - 1);                         // no child hit: child_dist = inf -> own (ray.rs:163-167)
+                    ret_t = (ret_slot != kNone) ? t_of_slot(S.geom + ret_slot, o, d) : kInf;
                     sp--;
                     returning = true;
                 }
                 if (sp == 0) { done = true; break; }
                 if (ret_slot != kNone) {                                 // a child returned Some -> `break` (ray.rs:155-160), then ray.rs:163-167
-                    const double pt = stk.own_t(sp - 1);
-                    if (!(ret_t < pt)) { ret_t = pt; ret_slot = stk.own_slot(sp - 1); }
+                    const uint32_t ps = stk.own_slot(sp - 1);               // the parent's `closest`: its own hit's t, else its threshold (ray.rs:117)
+                    const double pt = (ps != kNone) ? t_of_slot(S.geom + ps, o, d) : ((sp == 1) ? max_t : kInf);
+                    if (!(ret_t < pt)) { ret_t = pt; ret_slot = ps; }
                     sp--;
                 } else {
                     returning = false;                                   // child returned None -> try the next child
@@ -592,7 +604,10 @@ __device__ __forceinline__ uint32_t trace_colour(PROF_DECL const DevScene& S, co
 
 // ------------------------------------------------------------------------------------------------ kernels
 // One wave per workgroup; workgroup b renders quadrant (b & 3) of this rank's local tile (b >> 2).
-__global__ __launch_bounds__(64, 3) void render_kernel(const DevScene S, const FrameParams F, uint32_t* __restrict__ out) {
+#ifndef RRT_WAVES_PER_SIMD
+#define RRT_WAVES_PER_SIMD 5   // measured best on MI355X: 96 VGPRs (cold shading state spills to scratch), LDS stack 768 B/level/wave
+#endif
+__global__ __launch_bounds__(64, RRT_WAVES_PER_SIMD) void render_kernel(const DevScene S, const FrameParams F, uint32_t* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const uint32_t lane = threadIdx.x;
     const Stack stk{lds, lane};

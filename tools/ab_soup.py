@@ -1,0 +1,23 @@
+"""Developer tool: like ab_bench.py but on the 100k soup (config 3)."""
+import importlib, importlib.util, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+libs = sys.argv[1:]
+rts = []
+for i, path in enumerate(libs):
+    os.environ["RRT_LIB"] = os.path.abspath(path)
+    spec = importlib.util.spec_from_file_location(f"rrt_{i}", os.path.join(ROOT, "rust-ray-tracer_amd", "__init__.py"))
+    m = importlib.util.module_from_spec(spec); sys.modules[f"rrt_{i}"] = m; spec.loader.exec_module(m); m.lib()
+    if i == 0:
+        syn = importlib.import_module("rust-ray-tracer_amd.synthetic"); path_obj = syn.ensure_soup(os.path.join(ROOT, "assets"), 100000, syn.SEED_100K)
+    sd = m.parse_obj_file(path_obj)
+    rts.append(m.RayTracer(sd, m.default_lights()))
+frames = [rt.render(1920, 1080) for rt in rts]
+print("frames identical:", all(np.array_equal(frames[0], f) for f in frames[1:]))
+times = [[] for _ in rts]
+for r in range(7):
+    for i, rt in enumerate(rts):
+        rt.render(1920, 1080); times[i].append(rt.last_stats()["kernel_ms"])
+for path, t in zip(libs, times):
+    print(f"{os.path.basename(path):32s} median {np.median(t):.3f} ms  min {min(t):.3f}")
