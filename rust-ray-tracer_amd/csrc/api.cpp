@@ -345,7 +345,7 @@ int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n
             S.lights[i].v[0] = lights[i].v.x; S.lights[i].v[1] = lights[i].v.y; S.lights[i].v[2] = lights[i].v.z;
         }
 #ifdef RRT_PROFILE
-        { void* pb = nullptr; HIP_TRY(hipMalloc(&pb, 16 * sizeof(unsigned long long))); HIP_TRY(hipMemset(pb, 0, 16 * sizeof(unsigned long long)));
+        { void* pb = nullptr; HIP_TRY(hipMalloc(&pb, 24 * sizeof(unsigned long long))); HIP_TRY(hipMemset(pb, 0, 24 * sizeof(unsigned long long)));
           rt->allocs.push_back(pb); S.prof = static_cast<unsigned long long*>(pb); }
 #endif
         HIP_TRY(hipEventCreate(&rt->ev0)); HIP_TRY(hipEventCreate(&rt->ev1));
@@ -476,8 +476,8 @@ int rrt_prof_counters(rrt_raytracer* rt, unsigned long long* out16) {
     return guarded([&]() -> int {
         DeviceGuard guard(rt->device);
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(out16, rt->scene.prof, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemset(rt->scene.prof, 0, 16 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemcpy(out16, rt->scene.prof, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemset(rt->scene.prof, 0, 24 * sizeof(unsigned long long)));
         return RRT_OK;
     });
 }

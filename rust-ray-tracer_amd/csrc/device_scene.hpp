@@ -67,7 +67,7 @@ struct DevScene {                // passed to kernels by value (kernarg segment 
     uint32_t cull_enabled;
     DevLight lights[RRT_MAX_LIGHTS];
 #ifdef RRT_PROFILE
-    unsigned long long* prof;    // developer build only (make prof): 16 wave-level work counters, see tools/profile_counters.py
+    unsigned long long* prof;    // developer build only (make prof): 16 wave-level work counters + 8 s_memtime region timers, see tools/profile_counters.py
 #endif
 };
 

@@ -50,7 +50,24 @@ __device__ __forceinline__ double length(V3 a) { return sqrt(a.x * a.x + a.y * a
 __device__ __forceinline__ V3 cross(V3 a, V3 b) {                                                     // engine.rs:93-99
     return mk(a.y * b.z - a.z * b.y, -(a.x * b.z - a.z * b.x), a.x * b.y - a.y * b.x);
 }
-__device__ __forceinline__ V3 normalised(V3 a) { return a / length(a); }                              // engine.rs:101-103
+// (a.x/b, a.y/b, a.z/b), each correctly rounded exactly as the `/` operator rounds it.  hipcc lowers one f64 divide to
+//   s0 = div_scale(b,b,a); r = rcp(s0); two Newton steps on r; s1 = div_scale(a,b,a); q = s1*r; q = div_fmas(fma(-s0,q,s1), r, q); div_fixup(q,b,a)
+// and the first half depends on the denominator only whenever v_div_scale leaves its operands alone (every exponent within +-500 here).
+// Sharing it between the three numerators is therefore the SAME instruction sequence per quotient, 18 instructions instead of 39.
+__device__ __forceinline__ bool div_plain(double x) { const double a = fabs(x); return x == 0.0 || (a > 0x1p-500 && a < 0x1p500); }
+__device__ __forceinline__ V3 div3(V3 a, double b) {
+    const double ab = fabs(b);
+    if (!(ab > 0x1p-500 && ab < 0x1p500 && div_plain(a.x) && div_plain(a.y) && div_plain(a.z))) return mk(a.x / b, a.y / b, a.z / b);
+    double r = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, r, 1.0); r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-b, r, 1.0); r = __builtin_fma(r, e, r);
+    double qx = a.x * r, qy = a.y * r, qz = a.z * r;
+    qx = __builtin_fma(__builtin_fma(-b, qx, a.x), r, qx);
+    qy = __builtin_fma(__builtin_fma(-b, qy, a.y), r, qy);
+    qz = __builtin_fma(__builtin_fma(-b, qz, a.z), r, qz);
+    return mk(__builtin_amdgcn_div_fixup(qx, b, a.x), __builtin_amdgcn_div_fixup(qy, b, a.y), __builtin_amdgcn_div_fixup(qz, b, a.z));
+}
+__device__ __forceinline__ V3 normalised(V3 a) { return div3(a, length(a)); }                          // engine.rs:101-103
 
 // ------------------------------------------------------------------------------------------------ LDS stack
 // per wave: levels x 768 B, level record = own_slot[64] u32 | meta[64] u32 | fc[64] u32.  A frame does not keep the t of its own hit: the few
@@ -192,16 +209,17 @@ __device__ __forceinline__ bool slab_from_quotients(double t1, double t2, double
 // ------------------------------------------------------------------------------------------------ own-list index: fp32 box filter
 // The ray in fp32 for the conservative box filter over the cluster boxes of clusters.cpp: t = lo*inv - o*inv per slab as one FMA.
 // A direction component smaller than 1e-20 is treated as parallel (inv = 1e30): over any t that matters the ray does not move along
-// that axis by more than the box padding.  Rays with non-finite or out-of-scale components skip the filter (`nocull`).
-struct Ray32 { float ix, iy, iz, nx, ny, nz; bool nocull; };
+// that axis by more than the box padding.  Rays with non-finite or out-of-scale components (and every ray in RRT_FLAG_NO_CULL mode) get
+// inv = n = 0: all six slab values are then 0 and every box tests as hit, i.e. the filter is off for that lane.
+struct Ray32 { float ix, iy, iz, nx, ny, nz; };
 __device__ __forceinline__ Ray32 make_ray32(V3 o, V3 d, float limit, bool enabled) {
     const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z, dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
     Ray32 r;
-    r.nocull = !(enabled && fabsf(ox) < limit && fabsf(oy) < limit && fabsf(oz) < limit && fabsf(dx) < limit && fabsf(dy) < limit && fabsf(dz) < limit);
-    r.ix = fabsf(dx) < 1e-20f ? 1e30f : 1.0f / dx;
-    r.iy = fabsf(dy) < 1e-20f ? 1e30f : 1.0f / dy;
-    r.iz = fabsf(dz) < 1e-20f ? 1e30f : 1.0f / dz;
-    r.nx = -ox * r.ix; r.ny = -oy * r.iy; r.nz = -oz * r.iz;
+    const bool cull = enabled && fabsf(ox) < limit && fabsf(oy) < limit && fabsf(oz) < limit && fabsf(dx) < limit && fabsf(dy) < limit && fabsf(dz) < limit;
+    r.ix = !cull ? 0.0f : fabsf(dx) < 1e-20f ? 1e30f : 1.0f / dx;
+    r.iy = !cull ? 0.0f : fabsf(dy) < 1e-20f ? 1e30f : 1.0f / dy;
+    r.iz = !cull ? 0.0f : fabsf(dz) < 1e-20f ? 1e30f : 1.0f / dz;
+    r.nx = !cull ? 0.0f : -ox * r.ix; r.ny = !cull ? 0.0f : -oy * r.iy; r.nz = !cull ? 0.0f : -oz * r.iz;
     return r;
 }
 // true unless the ray (t >= 0) certainly misses the padded box; the box is wave-uniform
@@ -211,19 +229,21 @@ __device__ __forceinline__ bool slab32(const UBox& b, const Ray32& r) {
     const float az = __builtin_fmaf(b.loz, r.iz, r.nz), bz = __builtin_fmaf(b.hiz, r.iz, r.nz);
     const float tmin = fmaxf(fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)), 0.0f);
     const float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-    return r.nocull || tmin <= tmax;
+    return tmin <= tmax;
 }
 
 // ------------------------------------------------------------------------------------------------ developer counters
 #ifdef RRT_PROFILE
-struct Prof { unsigned long long c[16]; };
+struct Prof { unsigned long long c[16]; unsigned long long t[8]; unsigned long long last; };
 #define PROF_DECL Prof& prof,
 #define PROF_ARG prof,
 #define PROF_ADD(i, x) (prof.c[i] += (unsigned long long)(x))
+#define PROF_T(i) do { const unsigned long long _n = __builtin_amdgcn_s_memtime(); prof.t[i] += _n - prof.last; prof.last = _n; } while (0)
 #else
 #define PROF_DECL
 #define PROF_ARG
 #define PROF_ADD(i, x) ((void)0)
+#define PROF_T(i) ((void)0)
 #endif
 
 // ------------------------------------------------------------------------------------------------ traversal
@@ -246,14 +266,16 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
     const Ray32 r32 = make_ray32(o, d, S.cull_limit, S.cull_enabled != 0);
 
     PROF_ADD(6, 1); PROF_ADD(7, __popcll(__ballot(active)));
+    PROF_T(5);                                                           // [5] traverse set-up (ray32) + whatever ran since the last stamp outside
     for (;;) {
-        const unsigned long long pending = __ballot(!done);
+        const unsigned long long pending = __builtin_amdgcn_ballot_w64(!done);
         if (pending == 0) break;
         const int leader = __builtin_ctzll(pending);
         const uint32_t unode = __builtin_amdgcn_readlane(cur, leader);   // wave-uniform node id
         const UNode N = load_unode(nodes + unode);
         const uint32_t fc = N.first_child, sb = N.sup_begin, sc = N.sup_count, fl = N.flags;
         PROF_ADD(0, 1); PROF_ADD(1, __popcll(__ballot(!done && cur == unode)));
+        PROF_T(0);                                                       // [0] pick node + node record load
         if (!done && cur == unode) {
             bool returning;
             if (!(fl & 0x100u)) {                                        // triangle_count == 0 -> None, ray.rs:112-114
@@ -276,7 +298,7 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                             B.hix = mkf(v[off + 3]); B.hiy = mkf(v[off + 4]); B.hiz = mkf(v[off + 5]); B.a = 0; B.b = 0;           \
                             const bool h = slab32(B, r32);                                                                        \
                             lane_reach |= h ? (1u << k) : 0u;                                                                      \
-                            reach |= (__ballot(h) != 0) ? (1u << k) : 0u;                                                          \
+                            reach |= (__builtin_amdgcn_ballot_w64(h) != 0ull) ? (1u << k) : 0u;                                                          \
                         }
                         if (fl & 0x0Fu) { const u32x16 b01 = cbx[0], b23 = cbx[1]; RRT_CB(0, b01, 0) RRT_CB(1, b01, 8) RRT_CB(2, b23, 0) RRT_CB(3, b23, 8) }
                         if (fl & 0xF0u) { const u32x16 b45 = cbx[2], b67 = cbx[3]; RRT_CB(4, b45, 0) RRT_CB(5, b45, 8) RRT_CB(6, b67, 0) RRT_CB(7, b67, 8) }
@@ -323,6 +345,7 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                         if (vk[k]) { order |= (uint32_t)k << (3u * rank); nchild++; }
                     }
                 }
+                PROF_T(1);                                               // [1] children: reach filter, plane quotients, slab tests, rank
                 // ---- own list: ray.rs:119-129 as an arg-min over the list: super-cluster box -> its <= 8 cluster boxes -> triangles.
                 // A later list position never replaces an equal t (strict < in the reference keeps the first), so ties go to the smaller `pos`.
                 double own_t = (sp == 0) ? max_t : kInf;                 // ray.rs:117 (children are entered with +inf, ray.rs:96-102,153)
@@ -338,7 +361,7 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                         const bool hs = (sc == 1) || slab32(SP, r32);
                         const uint32_t tb = SP.a, tn = SP.b;
                         PROF_ADD(10, 1);
-                        if (__ballot(hs) != 0) {
+                        if (__builtin_amdgcn_ballot_w64(hs) != 0ull) {
                             // the (up to) 8 cluster boxes of this super-cluster in bursts of 4; cluster c covers slots tb+8c .. tb+8c+7
                             const RRT_CONSTANT u32x16* cb = (const RRT_CONSTANT u32x16*)(cboxes + (tb >> 3));
                             const uint32_t nc = (tn + 7u) >> 3;
@@ -350,7 +373,7 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                                 const bool h = hs && slab32(B, r32);                                                              \
                                 PROF_ADD(11, 1);                                                                                   \
                                 lane_hits |= h ? (1u << c) : 0u;                                                                   \
-                                wave_hits |= (__ballot(h) != 0) ? (1u << c) : 0u;                                                  \
+                                wave_hits |= (__builtin_amdgcn_ballot_w64(h) != 0ull) ? (1u << c) : 0u;                                                  \
                             }
                             {
                                 const u32x16 c01 = cb[0], c23 = cb[1];
@@ -377,7 +400,7 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                                     const bool h = hc && slab32(B, r32);                                                          \
                                     PROF_ADD(4, 1);                                                                                \
                                     lane_tri |= h ? (1u << i) : 0u;                                                                \
-                                    wave_tri |= (__ballot(h) != 0) ? (1u << i) : 0u;                                               \
+                                    wave_tri |= (__builtin_amdgcn_ballot_w64(h) != 0ull) ? (1u << i) : 0u;                                               \
                                 }
                                 {
                                     const u32x16 t01 = tbx[0], t23 = tbx[1];
@@ -410,6 +433,7 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                         SP = SN;
                     }
                 }
+                PROF_T(2);                                               // [2] own list: super/cluster/triangle boxes + Moller-Trumbore
                 // A shadow query at the root that already holds an own hit (t < max_t) returns Some whatever the children do
                 // (ray.rs:163-167 picks child or own, both Some), and only Some/None is used (raytracer.rs:183-187): stop here.
                 if (fc == 0 || (any_ok && sp == 0 && own_slot != kNone)) {   // leaf: no children -> returns its own result (ray.rs:163-167 with child_dist = inf)
@@ -420,6 +444,7 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                     returning = false;
                 }
             }
+            PROF_T(2);
             // unwind until this lane has a next node to enter or the root has returned (ray.rs:152-167)
             for (;;) {
                 if (!returning) {
@@ -445,8 +470,10 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                     returning = false;                                   // child returned None -> try the next child
                 }
             }
+            PROF_T(3);
         }
     }
+    PROF_T(3);                                                           // [3] stack push / unwind (attributed at traverse exit: includes the last unwind only)
     out_t = ret_t; out_slot = ret_slot;
 }
 
@@ -467,15 +494,21 @@ __device__ __forceinline__ uint32_t clamp_u8(double x) {       // clamp(0.0, 255
     if (!(x > 0.0)) return 0;
     return (uint32_t)x;
 }
-__device__ __forceinline__ V3 diffuse_term(double intensity, double n_dot_l, V3 normal, V3 l, V3 kd) {   // raytracer.rs:260-277
+// len_n = normal.length(), len_l = l.length(), len_v = v.length(): the reference recomputes them in every call (raytracer.rs:276,295); the
+// value is the same each time, so they are computed once per hit (len_n, len_v) / once per light (len_l) and passed in.
+__device__ __forceinline__ V3 diffuse_term(double intensity, double n_dot_l, double len_n, double len_l, V3 kd) {   // raytracer.rs:260-277
     if (n_dot_l <= 0.0) return mk(0.0, 0.0, 0.0);
-    return ((kd * intensity) * n_dot_l) / (length(normal) * length(l));
+    return div3((kd * intensity) * n_dot_l, len_n * len_l);
 }
-__device__ __forceinline__ V3 specular_term(double sw, double intensity, V3 normal, V3 v, V3 l, V3 ks) { // raytracer.rs:279-304
+__device__ __forceinline__ V3 specular_term(double sw, double intensity, V3 normal, V3 v, double len_v, V3 l, V3 ks) { // raytracer.rs:279-304
     if (sw != -1.0) {
         const V3 r = ((normal * 2.0) * dot(normal, l)) - l;
         const double r_dot_v = dot(r, v);
-        if (r_dot_v > 0.0) return (ks * intensity) * pow(r_dot_v / (length(r) * length(v)), sw);
+#ifdef RRT_ABL_NOPOW     /* ablation build only: timing experiment, wrong pixels */
+        if (r_dot_v > 0.0) return (ks * intensity) * (r_dot_v / (length(r) * len_v));
+#else
+        if (r_dot_v > 0.0) return (ks * intensity) * pow(r_dot_v / (length(r) * len_v), sw);
+#endif
     }
     return mk(0.0, 0.0, 0.0);
 }
@@ -487,12 +520,14 @@ __device__ __forceinline__ uint32_t trace_colour(PROF_DECL const DevScene& S, co
     V3 ro = origin, rd = direction; double rmax = kInf;
     V3 seg_d = direction;
     V3 p = mk(0, 0, 0), n = mk(0, 0, 0), I = mk(0, 0, 0);
+    double len_n = 0, len_v = 0;
     uint32_t col = 0, mat = 0, li = 0, depth = 0;
     uint32_t term = 0x00FFFFFFu;            // colour of the last segment
     double st_local[RRT_MAX_REFLECT][3]; double st_kr[RRT_MAX_REFLECT];
 
     while (__any(live)) {
         double t; uint32_t slot;
+        PROF_T(4);                                                       // [4] shading / state machine between traversals
         traverse(PROF_ARG S, stk, live, in_shadow, ro, rd, rmax, t, slot);
         if (live) {
             const bool found = slot != kNone;
@@ -526,13 +561,18 @@ __device__ __forceinline__ uint32_t trace_colour(PROF_DECL const DevScene& S, co
                         bv = normalised(bv);
                         bv = (bv * 2.0) - mk(1.0, 1.0, 1.0);                             // raytracer.rs:130-135
                         V3 tg = cross(nn, mk(0.0, 1.0, 0.0));                            // raytracer.rs:137-141
-                        if (length(tg) == 0.0) tg = cross(nn, mk(0.0, 0.0, 1.0));        // raytracer.rs:143-149
-                        tg = normalised(tg);
+                        double len_tg = length(tg);
+                        if (len_tg == 0.0) { tg = cross(nn, mk(0.0, 0.0, 1.0)); len_tg = length(tg); }   // raytracer.rs:143-149
+                        tg = div3(tg, len_tg);                                           // raytracer.rs:151 (t.length() again: same value)
                         const V3 bt = normalised(cross(nn, tg));                         // raytracer.rs:152
                         nn = mk(dot(bv, tg), dot(bv, bt), dot(bv, nn));                  // raytracer.rs:154-158
                     }
                     n = normalised(nn);                                                  // raytracer.rs:161
+                    len_n = length(n); len_v = length(rd);                               // |normal|, |v| = |-direction| for the light loop
                     I = mk(0.0, 0.0, 0.0); li = 0;                                       // compute_lighting_intensity, raytracer.rs:199-203
+#ifdef RRT_ABL_NOLIGHTS  /* ablation build only: primary hit set-up, then stop */
+                    li = S.n_lights; I = mk(1.0, 1.0, 1.0);
+#endif
                 }
             } else {
                 // --- result of the shadow ray for point light li, raytracer.rs:232-252
@@ -543,8 +583,8 @@ __device__ __forceinline__ uint32_t trace_colour(PROF_DECL const DevScene& S, co
                     const DevLight& L = S.lights[li];
                     const V3 l = ld3(L.v) - p;
                     const double n_dot_l = dot(n, l);
-                    I = I + diffuse_term(L.intensity, n_dot_l, n, l, ld3(M.kd));
-                    I = I + specular_term(M.ns, L.intensity, n, neg(seg_d), l, ld3(M.ks));
+                    I = I + diffuse_term(L.intensity, n_dot_l, len_n, rmax, ld3(M.kd));       // rmax = |position - point| from the shadow-ray set-up
+                    I = I + specular_term(M.ns, L.intensity, n, neg(seg_d), len_v, l, ld3(M.ks));
                     li++;
                 }
                 in_shadow = false;
@@ -560,8 +600,8 @@ __device__ __forceinline__ uint32_t trace_colour(PROF_DECL const DevScene& S, co
                     } else if (L.kind == 2u) {                                           // Directional, raytracer.rs:210-227
                         const V3 dir = ld3(L.v);
                         const double n_dot_l = dot(n, dir);
-                        I = I + diffuse_term(L.intensity, n_dot_l, n, dir, ld3(M.kd));
-                        I = I + specular_term(M.ns, L.intensity, n, neg(seg_d), dir, ld3(M.ks));
+                        I = I + diffuse_term(L.intensity, n_dot_l, len_n, length(dir), ld3(M.kd));
+                        I = I + specular_term(M.ns, L.intensity, n, neg(seg_d), len_v, dir, ld3(M.ks));
                         li++;
                     } else {                                                             // Point -> shadow ray, raytracer.rs:164-188
                         const V3 dir = ld3(L.v) - p;
@@ -630,11 +670,12 @@ __global__ __launch_bounds__(64, RRT_WAVES_PER_SIMD) void render_kernel(const De
     const double yd = (sub & 2u) ? ((double)y + 0.5) : (double)y;
     const V3 dir = mk(xd * F.x_scale, yd * F.y_scale, F.z_value);
 #ifdef RRT_PROFILE
-    Prof prof{};
+    Prof prof{}; prof.last = __builtin_amdgcn_s_memtime();
 #endif
     const uint32_t c = trace_colour(PROF_ARG S, stk, traced, ld3(S.origin), dir);
 #ifdef RRT_PROFILE
-    if (lane == 0) for (int i = 0; i < 16; i++) if (prof.c[i]) atomicAdd(S.prof + i, prof.c[i]);
+    PROF_T(4);
+    if (lane == 0) { for (int i = 0; i < 16; i++) if (prof.c[i]) atomicAdd(S.prof + i, prof.c[i]); for (int i = 0; i < 8; i++) if (prof.t[i]) atomicAdd(S.prof + 16 + i, prof.t[i]); }
 #endif
     // Color::mix over the 4 sub-samples of the pixel = 4 consecutive lanes (entities.rs:49-69): u64 sums, truncating /4
     uint32_t r = (c >> 16) & 255u, g = (c >> 8) & 255u, b = c & 255u;
@@ -668,7 +709,7 @@ __global__ __launch_bounds__(64) void ray_colour_kernel(const DevScene S, uint32
     const bool ok = i < n;
     const V3 o = ok ? ld3(origins + 3 * (size_t)i) : mk(0, 0, 0), d = ok ? ld3(dirs + 3 * (size_t)i) : mk(0, 0, 1);
 #ifdef RRT_PROFILE
-    Prof prof{};
+    Prof prof{}; prof.last = 0;
 #endif
     const uint32_t c = trace_colour(PROF_ARG S, stk, ok, o, d);
     if (ok) colours[i] = c;
@@ -685,7 +726,7 @@ __global__ __launch_bounds__(64) void intersect_kernel(const DevScene S, uint32_
     const double mt = (ok && max_t) ? max_t[i] : kInf;
     double t; uint32_t slot;
 #ifdef RRT_PROFILE
-    Prof prof{};
+    Prof prof{}; prof.last = 0;
 #endif
     traverse(PROF_ARG S, stk, ok, false, o, d, mt, t, slot);
     if (!ok) return;

@@ -12,7 +12,7 @@ sd = rrt.parse_obj_file(scene)
 rt = rrt.RayTracer(sd, rrt.default_lights())
 L = rrt.lib()
 L.rrt_prof_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
-buf = (C.c_uint64 * 16)()
+buf = (C.c_uint64 * 24)()
 rt.render(W, H); L.rrt_prof_counters(rt._h, buf)       # warm + clear
 rt.render(W, H); ms = rt.last_stats()["kernel_ms"]; L.rrt_prof_counters(rt._h, buf)
 c = list(buf)
@@ -20,5 +20,9 @@ names = ["node_visits(wave)", "node_visit_lanes", "tri_iters(wave)", "tri_lane_t
 for i, n in enumerate(names):
     print(f"{n:24s} {c[i]:>16,d}")
 print(f"kernel_ms (counters build) {ms:.2f}")
+tn = ["pick node + record load", "children (reach, quotients, slab, rank)", "own list (boxes + MT)", "push / unwind", "shading + state machine", "traverse set-up"]
+tt = sum(c[16:22]) or 1
+for i, n in enumerate(tn):
+    print(f"  time share {n:44s} {100.0 * c[16 + i] / tt:5.1f} %")
 print(f"lane utilisation in triangle loop: {c[3] / max(1, 64 * c[2]):.3f}   in slab tests: {c[9] / max(1, 64 * c[8]):.3f}   at node visits: {c[1] / max(1, 64 * c[0]):.3f}   at traverse(): {c[7] / max(1, 64 * c[6]):.3f}")
 print(f"wave-iterations per SIMD-second budget: tri {c[2]:,d} slab {c[8]:,d}; cycles/tri-iter if all time were the triangle loop: {ms*1e-3*2.4e9*1024/max(1,c[2]):.0f}")
