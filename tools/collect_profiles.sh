@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+BENCH="python3 $ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
 echo "trace rc=$?"
 # PMC passes kept separate (TCC slots: FETCH_SIZE 3, WRITE_SIZE 2 -- MI355X_MICROARCH.md) and never combined with tracing
