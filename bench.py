@@ -55,10 +55,18 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback in the product path)")
+    # RRT_BENCH_REHEARSAL=1: developer rehearsal of the N > 1 code path on a ONE-GPU box -- every rank uses GPU 0 and the collective runs
+    # over gloo (RCCL refuses two ranks on one device).  Never used by the driver; numbers from it are not benchmark results.
+    rehearsal = os.environ.get("RRT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     rrt = importlib.import_module("rust-ray-tracer_amd")
     W, H = args.width, args.height
@@ -205,7 +213,7 @@ def main() -> None:
                "config": {"workload": f"{os.path.basename(args.scene)} {W}x{H}, 4 sub-samples/pixel, shadow rays + depth-5 mirror reflection, f64",
                           "rays_primary_per_frame": rays_primary, "partition": "single launch" if world == 1 else f"8x8-pixel tiles round-robin over {world} GPUs + RCCL all-gather",
                           "octree_nodes": sd.info["n_nodes"], "triangles": sd.info["n_tris"]},
-               "frame_ms": round(ms_per_step, 4), "kernel_ms": round(kernel_ms, 4),
+               "frame_ms": round(ms_per_step, 4), "kernel_ms": round(kernel_ms, 4), **({"rehearsal": "gloo on one GPU: NOT a benchmark result"} if rehearsal else {}),
                "frame_checksum": int(np.bitwise_xor.reduce(frame.ravel().astype(np.uint64) * np.arange(1, frame.size + 1, dtype=np.uint64)))}
         if roofline is not None:
             out["roofline"] = roofline
