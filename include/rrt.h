@@ -53,6 +53,11 @@ typedef struct { const uint8_t *rgb; uint32_t width, height; } rrt_texture;
  * Default (0): the lists are indexed by padded cluster boxes that skip triangles a ray cannot reach; results are identical
  * (DESIGN.md section 4), tests compare the two modes bit for bit. */
 #define RRT_FLAG_NO_CULL 1u
+/* The index boxes are tested either by every ray against one box at a time (LANE filter) or by 64 boxes at a time against the wave's ray
+ * bundle (BUNDLE filter; faster on coherent rays, slower on scattered ones).  Both give the same pixels.  By default the first frame of
+ * every new frame size is rendered with both (a one-off stream synchronisation) and the faster is kept for that size; these flags force one. */
+#define RRT_FLAG_LANE_FILTER 2u
+#define RRT_FLAG_BUNDLE_FILTER 4u
 
 /* Render constants that the reference hard-codes; NULL => these defaults. */
 typedef struct {
@@ -74,6 +79,8 @@ typedef struct {
     uint32_t width, height;
     uint64_t rays_primary;            /* 4 * pixels actually traced */
     uint64_t scene_bytes;             /* bytes resident in HBM for this raytracer (geometry+octree+textures) */
+    uint32_t filter_variant;          /* 0 = LANE filter, 1 = BUNDLE filter (forced, or measured on the first frame of this size) */
+    uint32_t _pad;
 } rrt_stats;
 
 /* ------------------------------------------------------------------ model = SceneData (scenedata.rs:5-13), host side */

@@ -31,7 +31,7 @@ class RrtError(RuntimeError):
         self.detail = detail
 
 
-FLAG_NO_CULL = 1   # RRT_FLAG_NO_CULL, include/rrt.h
+FLAG_NO_CULL, FLAG_LANE_FILTER, FLAG_BUNDLE_FILTER = 1, 2, 4   # RRT_FLAG_*, include/rrt.h
 
 # status codes, include/rrt.h
 OK, ERR_INVALID_ARG, ERR_HIP, ERR_OOM, ERR_IO, ERR_PARSE, ERR_DEPTH, ERR_NO_DEVICE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7, -8
@@ -63,7 +63,8 @@ class CModelInfo(C.Structure):
 
 
 class CStats(C.Structure):
-    _fields_ = [("kernel_ms", C.c_double), ("width", C.c_uint32), ("height", C.c_uint32), ("rays_primary", C.c_uint64), ("scene_bytes", C.c_uint64)]
+    _fields_ = [("kernel_ms", C.c_double), ("width", C.c_uint32), ("height", C.c_uint32), ("rays_primary", C.c_uint64), ("scene_bytes", C.c_uint64),
+                ("filter_variant", C.c_uint32), ("_pad", C.c_uint32)]
 
 
 # every symbol include/rrt.h declares: (restype, argtypes)
@@ -259,13 +260,16 @@ class RayTracer:
     """RayTracer{scene_data, lights, origin} (raytracer.rs:22-26), uploaded once to one MI355X."""
 
     def __init__(self, scene_data: SceneData, lights: Iterable[Light], origin: Vector3d = DEFAULT_ORIGIN, device: int = 0,
-                 surface_offset: float = 0.0001, max_reflection_depth: int = 5, viewport=(1.0, 1.0, 1.0), no_cull: bool = False):
-        """no_cull=True (RRT_FLAG_NO_CULL): walk every own list in full, in list order, as ray.rs:119-129; default uses the cluster boxes."""
+                 surface_offset: float = 0.0001, max_reflection_depth: int = 5, viewport=(1.0, 1.0, 1.0), no_cull: bool = False,
+                 box_filter: Optional[str] = None):
+        """no_cull=True (RRT_FLAG_NO_CULL): walk every own list in full, in list order, as ray.rs:119-129; default uses the cluster boxes.
+        box_filter: None = measured at create, "lane" / "bundle" = forced (RRT_FLAG_LANE_FILTER / RRT_FLAG_BUNDLE_FILTER); same pixels."""
         self.scene_data, self.lights, self.origin, self.device = scene_data, list(lights), origin, device
         cl = (CLight * max(1, len(self.lights)))()
         for i, l in enumerate(self.lights):
             cl[i] = CLight(l.kind, 0, float(l.intensity), l.v._c())
-        opt = COptions(surface_offset, max_reflection_depth, FLAG_NO_CULL if no_cull else 0, *map(float, viewport))
+        flags = (FLAG_NO_CULL if no_cull else 0) | {None: 0, "lane": FLAG_LANE_FILTER, "bundle": FLAG_BUNDLE_FILTER}[box_filter]
+        opt = COptions(surface_offset, max_reflection_depth, flags, *map(float, viewport))
         out = _P()
         _check(lib().rrt_raytracer_create(scene_data._h, cl, len(self.lights), origin._c(), C.byref(opt), device, C.byref(out)), "rrt_raytracer_create")
         self._h = out

@@ -22,6 +22,9 @@ struct rrt_raytracer {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     rrt_stats stats{};
     bool stats_pending = false;
+    bool bundle = false;             // own-list filter variant used by this raytracer's launches (see rrt.h)
+    bool variant_forced = false;
+    uint32_t tuned_w = 0, tuned_h = 0, tuned_world = 0;
 };
 
 namespace rrt {
@@ -101,12 +104,31 @@ void check_frame(const rrt_raytracer* rt, uint32_t width, uint32_t height) {
     if (width == 0 || height == 0 || (uint64_t)width * height > 0x7FFFFFFFull) throw Error{RRT_ERR_INVALID_ARG, "bad frame size"};
 }
 
+// Both filter variants produce identical pixels; which is faster depends on how coherent the rays of a wave are (scene, camera, frame size).
+// So the first frame of every new frame size is rendered with both (each twice: the first run warms caches) on the caller's buffer and
+// stream, timed with HIP events, and the faster one is kept for that size.  This synchronises the stream once per new size.
+void tune_variant(rrt_raytracer* rt, const FrameParams& f, uint32_t* d_out, void* stream) {
+    if (rt->variant_forced || (rt->tuned_w == f.width && rt->tuned_h == f.height && rt->tuned_world == f.world)) return;
+    float ms[2] = {0, 0};
+    for (int variant = 0; variant < 2; variant++)
+        for (int rep = 0; rep < 2; rep++) {
+            HIP_TRY(hipEventRecord(rt->ev0, (hipStream_t)stream));
+            HIP_TRY((hipError_t)launch_render(rt->scene, f, d_out, stream, variant == 1));
+            HIP_TRY(hipEventRecord(rt->ev1, (hipStream_t)stream));
+            HIP_TRY(hipEventSynchronize(rt->ev1));
+            HIP_TRY(hipEventElapsedTime(&ms[variant], rt->ev0, rt->ev1));
+        }
+    rt->bundle = ms[1] < ms[0];
+    rt->tuned_w = f.width; rt->tuned_h = f.height; rt->tuned_world = f.world;
+}
+
 void record_launch(rrt_raytracer* rt, uint32_t width, uint32_t height, uint32_t rank, uint32_t world) {
     rt->stats.width = width; rt->stats.height = height;
     const uint64_t wt = 2ull * (width / 2), ht = height >= 2 ? (uint64_t)(2 * (height / 2) - 1) : 0;   // traced pixels: see render_kernel
     rt->stats.rays_primary = world == 1 ? 4ull * wt * ht : 0;   // per-rank share is not tracked
     (void)rank;
     rt->stats.scene_bytes = rt->scene_bytes;
+    rt->stats.filter_variant = rt->bundle ? 1u : 0u; rt->stats._pad = 0;
     rt->stats_pending = true;
 }
 
@@ -350,6 +372,9 @@ int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n
 #endif
         HIP_TRY(hipEventCreate(&rt->ev0)); HIP_TRY(hipEventCreate(&rt->ev1));
         HIP_TRY(hipDeviceSynchronize());
+        // Own-list filter variant: forced by a flag, else measured on the first frame of each frame size (tune_variant below)
+        rt->variant_forced = (o.flags & (RRT_FLAG_BUNDLE_FILTER | RRT_FLAG_LANE_FILTER | RRT_FLAG_NO_CULL)) != 0;
+        rt->bundle = (o.flags & RRT_FLAG_BUNDLE_FILTER) != 0 && !(o.flags & RRT_FLAG_NO_CULL);
         *out = rt.release();
         return RRT_OK;
     });
@@ -380,8 +405,9 @@ int rrt_render_tiles_device(rrt_raytracer* rt, uint32_t width, uint32_t height, 
         if (!d_tiles || world == 0 || rank >= world) throw Error{RRT_ERR_INVALID_ARG, "bad rank/world/buffer"};
         DeviceGuard guard(rt->device);
         const FrameParams f = frame_params(rt, width, height, rank, world, true);
+        tune_variant(rt, f, static_cast<uint32_t*>(d_tiles), stream);
         HIP_TRY(hipEventRecord(rt->ev0, (hipStream_t)stream));
-        HIP_TRY((hipError_t)launch_render(rt->scene, f, static_cast<uint32_t*>(d_tiles), stream));
+        HIP_TRY((hipError_t)launch_render(rt->scene, f, static_cast<uint32_t*>(d_tiles), stream, rt->bundle));
         HIP_TRY(hipEventRecord(rt->ev1, (hipStream_t)stream));
         record_launch(rt, width, height, rank, world);
         return RRT_OK;
@@ -394,8 +420,9 @@ int rrt_render_device(rrt_raytracer* rt, uint32_t width, uint32_t height, void* 
         if (!d_fb) throw Error{RRT_ERR_INVALID_ARG, "null framebuffer"};
         DeviceGuard guard(rt->device);
         const FrameParams f = frame_params(rt, width, height, 0, 1, false);
+        tune_variant(rt, f, static_cast<uint32_t*>(d_fb), stream);
         HIP_TRY(hipEventRecord(rt->ev0, (hipStream_t)stream));
-        HIP_TRY((hipError_t)launch_render(rt->scene, f, static_cast<uint32_t*>(d_fb), stream));
+        HIP_TRY((hipError_t)launch_render(rt->scene, f, static_cast<uint32_t*>(d_fb), stream, rt->bundle));
         HIP_TRY(hipEventRecord(rt->ev1, (hipStream_t)stream));
         record_launch(rt, width, height, 0, 1);
         return RRT_OK;
@@ -439,7 +466,7 @@ int rrt_get_ray_colours(rrt_raytracer* rt, uint32_t n, const double* origins, co
         HIP_TRY(hipMalloc((void**)&d_o, sizeof(double) * 3 * (size_t)n)); HIP_TRY(hipMalloc((void**)&d_d, sizeof(double) * 3 * (size_t)n)); HIP_TRY(hipMalloc((void**)&d_c, sizeof(uint32_t) * (size_t)n));
         HIP_TRY(hipMemcpy(d_o, origins, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d_d, dirs, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice));
-        HIP_TRY((hipError_t)launch_ray_colours(rt->scene, n, d_o, d_d, d_c, nullptr));
+        HIP_TRY((hipError_t)launch_ray_colours(rt->scene, n, d_o, d_d, d_c, nullptr, rt->bundle));
         HIP_TRY(hipMemcpy(colours, d_c, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost));
         return (int)RRT_OK;
     });
@@ -460,7 +487,7 @@ int rrt_intersect_rays(rrt_raytracer* rt, uint32_t n, const double* origins, con
         HIP_TRY(hipMemcpy(bufs[1], dirs, 24 * N, hipMemcpyHostToDevice));
         if (max_t) HIP_TRY(hipMemcpy(bufs[2], max_t, 8 * N, hipMemcpyHostToDevice));
         HIP_TRY((hipError_t)launch_intersect(rt->scene, n, (const double*)bufs[0], (const double*)bufs[1], max_t ? (const double*)bufs[2] : nullptr,
-                                             (uint8_t*)bufs[3], (double*)bufs[4], (double*)bufs[5], (double*)bufs[6], (uint32_t*)bufs[7], nullptr));
+                                             (uint8_t*)bufs[3], (double*)bufs[4], (double*)bufs[5], (double*)bufs[6], (uint32_t*)bufs[7], nullptr, rt->bundle));
         HIP_TRY(hipMemcpy(hit, bufs[3], N, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(t, bufs[4], 8 * N, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(u, bufs[5], 8 * N, hipMemcpyDeviceToHost));
@@ -495,6 +522,7 @@ int rrt_last_stats(const rrt_raytracer* rt_c, rrt_stats* out) {
             rt->stats.kernel_ms = ms;
             rt->stats_pending = false;
         }
+        rt->stats.filter_variant = rt->bundle ? 1u : 0u;
         *out = rt->stats;
         return RRT_OK;
     });

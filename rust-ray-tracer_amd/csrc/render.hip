@@ -259,10 +259,76 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+__device__ __forceinline__ float wave_min_f32(float v) {
+    const int id = 0x7F800000;   // +inf
+#define RRT_STEP(ctrl, rm) v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(id, __builtin_bit_cast(int, v), ctrl, rm, 0xf, false)))
+    RRT_STEP(0x111, 0xf); RRT_STEP(0x112, 0xf); RRT_STEP(0x114, 0xf); RRT_STEP(0x118, 0xf); RRT_STEP(0x142, 0xa); RRT_STEP(0x143, 0xc);
+#undef RRT_STEP
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_max_f32(float v) { return -wave_min_f32(-v); }
+
+// ---- the wave's ray bundle, for the boxes-in-lanes filter (RRT_BUNDLE).  A slab value of lane l is a_l(b) = b*inv_l - o_l*inv_l
+// = (b - c)*inv_l + m_l with m_l = (c - o_l)*inv_l and c a common reference point (the first active lane's origin: m_l = 0 for a bundle
+// with one origin).  With inv_l in [imin, imax] (same sign) and m_l in [mmin, mmax], a_l(b) lies in (b-c)*[imin,imax] + [mmin,mmax]: an
+// interval that bounds every lane's near/far slab values, so a box whose interval test fails is missed by every lane's own test.
+struct Bundle { float cx, cy, cz, ilx, ihx, ily, ihy, ilz, ihz, mlx, mhx, mly, mhy, mlz, mhz; bool off, ubx, uby, ubz; };
+__device__ __forceinline__ Bundle make_bundle(bool active, V3 o, const Ray32& r) {
+    Bundle B;
+    const unsigned long long act = __builtin_amdgcn_ballot_w64(active);
+    const int leader = act ? __builtin_ctzll(act) : 0;
+    const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
+    B.cx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ox), leader));
+    B.cy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, oy), leader));
+    B.cz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, oz), leader));
+    const float mx = (B.cx - ox) * r.ix, my = (B.cy - oy) * r.iy, mz = (B.cz - oz) * r.iz;
+    const float pinf = __builtin_huge_valf();
+    B.ilx = wave_min_f32(active ? r.ix : pinf); B.ihx = wave_max_f32(active ? r.ix : -pinf);
+    B.ily = wave_min_f32(active ? r.iy : pinf); B.ihy = wave_max_f32(active ? r.iy : -pinf);
+    B.ilz = wave_min_f32(active ? r.iz : pinf); B.ihz = wave_max_f32(active ? r.iz : -pinf);
+    B.mlx = wave_min_f32(active ? mx : pinf); B.mhx = wave_max_f32(active ? mx : -pinf);
+    B.mly = wave_min_f32(active ? my : pinf); B.mhy = wave_max_f32(active ? my : -pinf);
+    B.mlz = wave_min_f32(active ? mz : pinf); B.mhz = wave_max_f32(active ? mz : -pinf);
+    // an axis whose directions have mixed signs in the wave gives no bound; a lane with the filter off (inv = 0) switches the bundle test off
+    B.ubx = B.ilx < 0.0f && B.ihx > 0.0f; B.uby = B.ily < 0.0f && B.ihy > 0.0f; B.ubz = B.ilz < 0.0f && B.ihz > 0.0f;
+    B.off = act == 0ull || __builtin_amdgcn_ballot_w64(active && r.ix == 0.0f && r.iy == 0.0f && r.iz == 0.0f) != 0ull;
+    return B;
+}
+// per-LANE box (lo/hi in VGPRs) against the bundle: false only if no active lane's own slab test could pass
+__device__ __forceinline__ bool bundle_hit(const Bundle& B, float lox, float loy, float loz, float hix, float hiy, float hiz) {
+    float tn = 0.0f, tf = __builtin_huge_valf();
+#define RRT_AX(lo, hi, c, il, ih, ml, mh, ub)                                                                  \
+    if (!ub) {                                                                                                  \
+        const float pl = lo - c, ph = hi - c;                                                                   \
+        const float a1 = pl * il, a2 = pl * ih, b1 = ph * il, b2 = ph * ih;                                     \
+        tn = fmaxf(tn, fminf(fminf(a1, a2), fminf(b1, b2)) + ml);                                               \
+        tf = fminf(tf, fmaxf(fmaxf(a1, a2), fmaxf(b1, b2)) + mh);                                               \
+    }
+    RRT_AX(lox, hix, B.cx, B.ilx, B.ihx, B.mlx, B.mhx, B.ubx)
+    RRT_AX(loy, hiy, B.cy, B.ily, B.ihy, B.mly, B.mhy, B.uby)
+    RRT_AX(loz, hiz, B.cz, B.ilz, B.ihz, B.mlz, B.mhz, B.ubz)
+#undef RRT_AX
+    return B.off || tn <= tf;
+}
+// stream compaction across the wave (all 64 lanes must execute it): entry k of the survivors ends up in lane k; returns their number
+__device__ __forceinline__ uint32_t wave_compact2(bool keep, uint32_t a, uint32_t b, uint32_t lane, uint32_t& out_a, uint32_t& out_b) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+    const uint32_t n = (uint32_t)__popcll(m);
+    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));   // kept lanes below this one
+    const uint32_t dest = keep ? below : n + (lane - below);                                                            // a permutation of 0..63
+    out_a = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest << 2), (int)a);
+    out_b = (uint32_t)__builtin_amdgcn_ds_permute((int)(dest << 2), (int)b);
+    return n;
+}
+__device__ __forceinline__ uint32_t lane_read(uint32_t v, uint32_t src_lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v); }
+
 // Ray::intersect_with_octant_with_max_t(octree, 0, max_t), ray.rs:104-168, for all 64 lanes at once.
 // Must be called from wave-uniform control flow; lanes with active == false take no part.
 // Result: slot == kNone <=> None; otherwise (t, slot) of the returned triangle.
 // any_ok: the caller only uses Some/None of the result (shadow query, raytracer.rs:181-187).
+// kBundle selects the own-list filter: false = every lane tests each box against its own ray (64 rays x 1 box per instruction);
+// true = boxes in lanes against the wave's ray bundle (64 boxes x 1 bundle per instruction).  Same results either way.
+template <bool kBundle>
 __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stack& stk, bool active, bool any_ok, V3 o, V3 d, double max_t,
                                          double& out_t, uint32_t& out_slot) {
     bool done = !active;
@@ -276,6 +342,8 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
     const RRT_CONSTANT DevClusterBox* child_boxes = (const RRT_CONSTANT DevClusterBox*)S.child_boxes;
     const RRT_CONSTANT DevClusterBox* tboxes = (const RRT_CONSTANT DevClusterBox*)S.tboxes;
     const Ray32 r32 = make_ray32(o, d, S.cull_limit, S.cull_enabled != 0);
+    Bundle BU{};
+    if constexpr (kBundle) BU = make_bundle(active, o, r32);
 
     PROF_ADD(6, 1); PROF_ADD(7, __popcll(__ballot(active)));
     PROF_T(5);                                                           // [5] traverse set-up (ray32) + whatever ran since the last stamp outside
@@ -292,15 +360,13 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
         const uint32_t fc = N.first_child, sb = N.sup_begin, sc = N.sup_count, fl = N.flags;
         PROF_ADD(0, 1); PROF_ADD(1, __popcll(__ballot(!done && cur == unode)));
         PROF_T(0);                                                       // [0] pick node + node record load
-        if (!done && cur == unode) {
-            bool returning;
-            if (!(fl & 0x100u)) {                                        // triangle_count == 0 -> None, ray.rs:112-114
-                returning = true; ret_slot = kNone; ret_t = kInf;
-            } else {
+        const bool mine = !done && cur == unode;
+        uint32_t order = 0, nchild = 0;
+        if (mine && (fl & 0x100u)) {
+            {
                 // ---- children first (their boxes are this node's lo/mid/hi, which can then leave the SGPRs): slab test in child order
                 // (ray.rs:135-144).  Children whose triangle_count is 0 return None at once (ray.rs:112) and dropping entries does not disturb a
                 // stable sort, so they are skipped untested.
-                uint32_t order = 0, nchild = 0;
                 if (fc != 0) {
                     PROF_ADD(12, 1);
                     // (1) conservative fp32 filter against the TIGHT bounds of each non-empty child's subtree (clusters.cpp): a child the ray cannot
@@ -361,106 +427,171 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                         if (vk[k]) { order |= (uint32_t)k << (3u * rank); nchild++; }
                     }
                 }
-                PROF_T(1);                                               // [1] children: reach filter, plane quotients, slab tests, rank
-                // ---- own list: ray.rs:119-129 as an arg-min over the list: super-cluster box -> its <= 8 cluster boxes -> triangles.
-                // A later list position never replaces an equal t (strict < in the reference keeps the first), so ties go to the smaller `pos`.
-                double own_t = (sp == 0) ? max_t : kInf;                 // ray.rs:117 (children are entered with +inf, ray.rs:96-102,153)
-                uint32_t own_slot = kNone;
-                uint32_t own_pos = 0;
+            }
+        }
+        PROF_T(1);                                                       // [1] children: reach filter, plane quotients, slab tests, rank
+        // ---- own list: ray.rs:119-129 as an arg-min over the list: super-cluster box -> its <= 8 cluster boxes -> triangle boxes -> triangles.
+        // A later list position never replaces an equal t (strict < in the reference keeps the first), so ties go to the smaller `pos`.
+        double own_t = (sp == 0) ? max_t : kInf;                         // ray.rs:117 (children are entered with +inf, ray.rs:96-102,153)
+        uint32_t own_slot = kNone;
+        uint32_t own_pos = 0;
+        // Boxes in lanes: all 64 lanes work here (wave-uniform control flow), each lane testing ONE box of the current level against the
+        // wave's ray bundle; survivors are compacted and expanded to the next level; only the triangles that survive are tested, by the
+        // lanes parked at this node.
+        if constexpr (kBundle) {
+        if ((fl & 0x100u) && sc) {
+            const uint32_t lane = stk.lane, sub = lane & 7u, grp = lane >> 3;
+            for (uint32_t s0 = 0; s0 < sc; s0 += 64u) {
+                uint32_t l1a = N.s0_begin, l1b = N.s0_count, n1 = 1;             // a single super-cluster: its slot range is in the node record
+                if (sc > 1u) {
+                    const uint32_t si = s0 + lane;
+                    bool h = false; uint32_t tb = 0, tn = 0;
+                    if (si < sc) {
+                        const DevSuper* P = S.supers + sb + si;
+                        h = bundle_hit(BU, P->lo[0], P->lo[1], P->lo[2], P->hi[0], P->hi[1], P->hi[2]); tb = P->tri_begin; tn = P->tri_count;
+                    }
+                    PROF_ADD(10, 1);
+                    n1 = wave_compact2(h, tb, tn, lane, l1a, l1b);
+                }
+                for (uint32_t e0 = 0; e0 < n1; e0 += 8u) {                      // 8 super-clusters x 8 clusters per batch
+                    const uint32_t e = e0 + grp;
+                    const uint32_t etb = lane_read(l1a, e < n1 ? e : 0u), etn = lane_read(l1b, e < n1 ? e : 0u);
+                    bool h2 = false;
+                    if (e < n1 && sub * 8u < etn) {
+                        const DevClusterBox* P = S.cboxes + (etb >> 3) + sub;
+                        h2 = bundle_hit(BU, P->lo[0], P->lo[1], P->lo[2], P->hi[0], P->hi[1], P->hi[2]);
+                    }
+                    PROF_ADD(11, 1);
+                    uint32_t l2a, l2b;
+                    const uint32_t n2 = wave_compact2(h2, etb + 8u * sub, (etn - 8u * sub < 8u) ? etn - 8u * sub : 8u, lane, l2a, l2b);
+                    for (uint32_t f0 = 0; f0 < n2; f0 += 8u) {                  // 8 clusters x 8 triangles per batch
+                        const uint32_t f = f0 + grp;
+                        const uint32_t fs = lane_read(l2a, f < n2 ? f : 0u), fn = lane_read(l2b, f < n2 ? f : 0u);
+                        bool h3 = false;
+                        if (f < n2 && sub < fn) {
+                            const DevClusterBox* P = S.tboxes + fs + sub;
+                            h3 = bundle_hit(BU, P->lo[0], P->lo[1], P->lo[2], P->hi[0], P->hi[1], P->hi[2]);
+                        }
+                        PROF_ADD(4, 1);
+                        uint32_t l3a, l3b;
+                        const uint32_t n3 = wave_compact2(h3, fs + sub, 0u, lane, l3a, l3b);
+                        if (n3) {
+                            uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)l3a, 0);
+                            UTri tri = load_utri(geom + slot);
+                            for (uint32_t i = 0; i < n3; ++i) {
+                                UTri nxt = tri; uint32_t slot_n = slot;
+                                if (i + 1 < n3) { slot_n = (uint32_t)__builtin_amdgcn_readlane((int)l3a, (int)(i + 1)); nxt = load_utri(geom + slot_n); }   // scalar prefetch
+                                double t;
+                                PROF_ADD(2, 1); PROF_ADD(3, __popcll(__ballot(mine)));
+                                if (mine && mt_uniform(tri, o, d, t) && (t < own_t || (t == own_t && tri.pos < own_pos))) { own_t = t; own_slot = slot; own_pos = tri.pos; }
+                                tri = nxt; slot = slot_n;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        } else {
+        if (mine && (fl & 0x100u)) {
                 if (sc) {
-                    // a node with a single super-cluster carries its slot range in the node record and skips the super-cluster box
-                    UBox SP; SP.a = N.s0_begin; SP.b = N.s0_count; SP.lox = SP.loy = SP.loz = SP.hix = SP.hiy = SP.hiz = 0.0f;
-                    if (sc > 1) SP = load_ubox(supers + sb);
-                    for (uint32_t si = 0; si < sc; ++si) {
-                        UBox SN = SP;
-                        if (si + 1 < sc) SN = load_ubox(supers + sb + si + 1);                            // scalar prefetch of the next super-cluster
-                        const bool hs = (sc == 1) || slab32(SP, r32);
-                        const uint32_t tb = SP.a, tn = SP.b;
-                        PROF_ADD(10, 1);
-                        if (__builtin_amdgcn_ballot_w64(hs) != 0ull) {
-                            // the (up to) 8 cluster boxes of this super-cluster in bursts of 4; cluster c covers slots tb+8c .. tb+8c+7
-                            const RRT_CONSTANT u32x16* cb = (const RRT_CONSTANT u32x16*)(cboxes + (tb >> 3));
-                            const uint32_t nc = (tn + 7u) >> 3;
-                            uint32_t lane_hits = 0, wave_hits = 0;
+                // a node with a single super-cluster carries its slot range in the node record and skips the super-cluster box
+                UBox SP; SP.a = N.s0_begin; SP.b = N.s0_count; SP.lox = SP.loy = SP.loz = SP.hix = SP.hiy = SP.hiz = 0.0f;
+                if (sc > 1) SP = load_ubox(supers + sb);
+                for (uint32_t si = 0; si < sc; ++si) {
+                    UBox SN = SP;
+                    if (si + 1 < sc) SN = load_ubox(supers + sb + si + 1);                            // scalar prefetch of the next super-cluster
+                    const bool hs = (sc == 1) || slab32(SP, r32);
+                    const uint32_t tb = SP.a, tn = SP.b;
+                    PROF_ADD(10, 1);
+                    if (__builtin_amdgcn_ballot_w64(hs) != 0ull) {
+                        // the (up to) 8 cluster boxes of this super-cluster in bursts of 4; cluster c covers slots tb+8c .. tb+8c+7
+                        const RRT_CONSTANT u32x16* cb = (const RRT_CONSTANT u32x16*)(cboxes + (tb >> 3));
+                        const uint32_t nc = (tn + 7u) >> 3;
+                        uint32_t lane_hits = 0, wave_hits = 0;
 #define RRT_CL(c, v, off)                                                                                                          \
-                            if (c < nc) {                                                                                          \
-                                UBox B; B.lox = mkf(v[off]); B.loy = mkf(v[off + 1]); B.loz = mkf(v[off + 2]);                     \
-                                B.hix = mkf(v[off + 3]); B.hiy = mkf(v[off + 4]); B.hiz = mkf(v[off + 5]); B.a = 0; B.b = 0;       \
-                                const bool h = hs && slab32(B, r32);                                                              \
-                                PROF_ADD(11, 1);                                                                                   \
-                                lane_hits |= h ? (1u << c) : 0u;                                                                   \
-                                wave_hits |= (__builtin_amdgcn_ballot_w64(h) != 0ull) ? (1u << c) : 0u;                                                  \
+                        if (c < nc) {                                                                                          \
+                            UBox B; B.lox = mkf(v[off]); B.loy = mkf(v[off + 1]); B.loz = mkf(v[off + 2]);                     \
+                            B.hix = mkf(v[off + 3]); B.hiy = mkf(v[off + 4]); B.hiz = mkf(v[off + 5]); B.a = 0; B.b = 0;       \
+                            const bool h = hs && slab32(B, r32);                                                              \
+                            PROF_ADD(11, 1);                                                                                   \
+                            lane_hits |= h ? (1u << c) : 0u;                                                                   \
+                            wave_hits |= (__builtin_amdgcn_ballot_w64(h) != 0ull) ? (1u << c) : 0u;                                                  \
+                        }
+                        {
+                            const u32x16 c01 = cb[0], c23 = cb[1];
+                            RRT_CL(0u, c01, 0) RRT_CL(1u, c01, 8) RRT_CL(2u, c23, 0) RRT_CL(3u, c23, 8)
+                        }
+                        if (nc > 4u) {
+                            const u32x16 c45 = cb[2], c67 = cb[3];
+                            RRT_CL(4u, c45, 0) RRT_CL(5u, c45, 8) RRT_CL(6u, c67, 0) RRT_CL(7u, c67, 8)
+                        }
+#undef RRT_CL
+                        while (wave_hits) {
+                            const uint32_t c = __builtin_ctz(wave_hits);
+                            wave_hits &= wave_hits - 1u;
+                            const bool hc = (lane_hits >> c) & 1u;
+                            const uint32_t cb0 = tb + 8u * c, cn = (tn - 8u * c < 8u) ? tn - 8u * c : 8u;
+                            // per-triangle boxes of this cluster (same conservative fp32 filter, one level down): only triangles whose box some
+                            // lane may hit are fetched (80-byte f64 records) and tested
+                            const RRT_CONSTANT u32x16* tbx = (const RRT_CONSTANT u32x16*)(tboxes + cb0);
+                            uint32_t lane_tri = 0, wave_tri = 0;
+#define RRT_TB(i, v, off)                                                                                                          \
+                            if (i < cn) {                                                                                      \
+                                UBox B; B.lox = mkf(v[off]); B.loy = mkf(v[off + 1]); B.loz = mkf(v[off + 2]);                 \
+                                B.hix = mkf(v[off + 3]); B.hiy = mkf(v[off + 4]); B.hiz = mkf(v[off + 5]); B.a = 0; B.b = 0;   \
+                                const bool h = hc && slab32(B, r32);                                                          \
+                                PROF_ADD(4, 1);                                                                                \
+                                lane_tri |= h ? (1u << i) : 0u;                                                                \
+                                wave_tri |= (__builtin_amdgcn_ballot_w64(h) != 0ull) ? (1u << i) : 0u;                                               \
                             }
                             {
-                                const u32x16 c01 = cb[0], c23 = cb[1];
-                                RRT_CL(0u, c01, 0) RRT_CL(1u, c01, 8) RRT_CL(2u, c23, 0) RRT_CL(3u, c23, 8)
+                                const u32x16 t01 = tbx[0], t23 = tbx[1];
+                                RRT_TB(0u, t01, 0) RRT_TB(1u, t01, 8) RRT_TB(2u, t23, 0) RRT_TB(3u, t23, 8)
                             }
-                            if (nc > 4u) {
-                                const u32x16 c45 = cb[2], c67 = cb[3];
-                                RRT_CL(4u, c45, 0) RRT_CL(5u, c45, 8) RRT_CL(6u, c67, 0) RRT_CL(7u, c67, 8)
+                            if (cn > 4u) {
+                                const u32x16 t45 = tbx[2], t67 = tbx[3];
+                                RRT_TB(4u, t45, 0) RRT_TB(5u, t45, 8) RRT_TB(6u, t67, 0) RRT_TB(7u, t67, 8)
                             }
-#undef RRT_CL
-                            while (wave_hits) {
-                                const uint32_t c = __builtin_ctz(wave_hits);
-                                wave_hits &= wave_hits - 1u;
-                                const bool hc = (lane_hits >> c) & 1u;
-                                const uint32_t cb0 = tb + 8u * c, cn = (tn - 8u * c < 8u) ? tn - 8u * c : 8u;
-                                // per-triangle boxes of this cluster (same conservative fp32 filter, one level down): only triangles whose box some
-                                // lane may hit are fetched (80-byte f64 records) and tested
-                                const RRT_CONSTANT u32x16* tbx = (const RRT_CONSTANT u32x16*)(tboxes + cb0);
-                                uint32_t lane_tri = 0, wave_tri = 0;
-#define RRT_TB(i, v, off)                                                                                                          \
-                                if (i < cn) {                                                                                      \
-                                    UBox B; B.lox = mkf(v[off]); B.loy = mkf(v[off + 1]); B.loz = mkf(v[off + 2]);                 \
-                                    B.hix = mkf(v[off + 3]); B.hiy = mkf(v[off + 4]); B.hiz = mkf(v[off + 5]); B.a = 0; B.b = 0;   \
-                                    const bool h = hc && slab32(B, r32);                                                          \
-                                    PROF_ADD(4, 1);                                                                                \
-                                    lane_tri |= h ? (1u << i) : 0u;                                                                \
-                                    wave_tri |= (__builtin_amdgcn_ballot_w64(h) != 0ull) ? (1u << i) : 0u;                                               \
-                                }
-                                {
-                                    const u32x16 t01 = tbx[0], t23 = tbx[1];
-                                    RRT_TB(0u, t01, 0) RRT_TB(1u, t01, 8) RRT_TB(2u, t23, 0) RRT_TB(3u, t23, 8)
-                                }
-                                if (cn > 4u) {
-                                    const u32x16 t45 = tbx[2], t67 = tbx[3];
-                                    RRT_TB(4u, t45, 0) RRT_TB(5u, t45, 8) RRT_TB(6u, t67, 0) RRT_TB(7u, t67, 8)
-                                }
 #undef RRT_TB
-                                if (wave_tri) {
-                                    uint32_t s = __builtin_ctz(wave_tri);
+                            if (wave_tri) {
+                                uint32_t s = __builtin_ctz(wave_tri);
+                                wave_tri &= wave_tri - 1u;
+                                UTri tri = load_utri(geom + cb0 + s);
+                                for (;;) {
+                                    const uint32_t s_next = wave_tri ? (uint32_t)__builtin_ctz(wave_tri) : s;
+                                    UTri nxt = tri;
+                                    if (wave_tri) nxt = load_utri(geom + cb0 + s_next);                 // scalar prefetch of the next candidate triangle
+                                    double t;
+                                    const bool ht = (lane_tri >> s) & 1u;
+                                    PROF_ADD(2, 1); PROF_ADD(3, __popcll(__ballot(ht)));
+                                    if (ht && mt_uniform(tri, o, d, t) && (t < own_t || (t == own_t && tri.pos < own_pos))) { own_t = t; own_slot = cb0 + s; own_pos = tri.pos; }
+                                    if (!wave_tri) break;
                                     wave_tri &= wave_tri - 1u;
-                                    UTri tri = load_utri(geom + cb0 + s);
-                                    for (;;) {
-                                        const uint32_t s_next = wave_tri ? (uint32_t)__builtin_ctz(wave_tri) : s;
-                                        UTri nxt = tri;
-                                        if (wave_tri) nxt = load_utri(geom + cb0 + s_next);                 // scalar prefetch of the next candidate triangle
-                                        double t;
-                                        const bool ht = (lane_tri >> s) & 1u;
-                                        PROF_ADD(2, 1); PROF_ADD(3, __popcll(__ballot(ht)));
-                                        if (ht && mt_uniform(tri, o, d, t) && (t < own_t || (t == own_t && tri.pos < own_pos))) { own_t = t; own_slot = cb0 + s; own_pos = tri.pos; }
-                                        if (!wave_tri) break;
-                                        wave_tri &= wave_tri - 1u;
-                                        tri = nxt; s = s_next;
-                                    }
+                                    tri = nxt; s = s_next;
                                 }
                             }
                         }
-                        SP = SN;
                     }
-                }
-                PROF_T(2);                                               // [2] own list: super/cluster/triangle boxes + Moller-Trumbore
-                // A shadow query at the root that already holds an own hit (t < max_t) returns Some whatever the children do
-                // (ray.rs:163-167 picks child or own, both Some), and only Some/None is used (raytracer.rs:183-187): stop here.
-                if (fc == 0 || (any_ok && sp == 0 && own_slot != kNone)) {   // leaf: no children -> returns its own result (ray.rs:163-167 with child_dist = inf)
-                    returning = true; ret_slot = own_slot; ret_t = own_t;
-                } else {
-                    stk.own_slot(sp) = own_slot; stk.meta(sp) = order | (nchild << 24); stk.fc(sp) = fc;
-                    sp++;
-                    returning = false;
+                    SP = SN;
                 }
             }
-            PROF_T(2);
+        }
+        }
+        PROF_T(2);                                                       // [2] own list: boxes + Moller-Trumbore
+        if (mine) {
+            bool returning;
+            if (!(fl & 0x100u)) {                                        // triangle_count == 0 -> None, ray.rs:112-114
+                returning = true; ret_slot = kNone; ret_t = kInf;
+            }
+            // A shadow query at the root that already holds an own hit (t < max_t) returns Some whatever the children do
+            // (ray.rs:163-167 picks child or own, both Some), and only Some/None is used (raytracer.rs:183-187): stop here.
+            else if (fc == 0 || (any_ok && sp == 0 && own_slot != kNone)) {   // leaf: no children -> returns its own result (ray.rs:163-167 with child_dist = inf)
+                returning = true; ret_slot = own_slot; ret_t = own_t;
+            } else {
+                stk.own_slot(sp) = own_slot; stk.meta(sp) = order | (nchild << 24); stk.fc(sp) = fc;
+                sp++;
+                returning = false;
+            }
             // unwind until this lane has a next node to enter or the root has returned (ray.rs:152-167)
             for (;;) {
                 if (!returning) {
@@ -530,6 +661,7 @@ __device__ __forceinline__ V3 specular_term(double sw, double intensity, V3 norm
 }
 
 // RayTracer::get_ray_colour (raytracer.rs:29-112) for 64 lanes; wave-uniform call.  Returns 0x00RRGGBB.
+template <bool kBundle>
 __device__ __forceinline__ uint32_t trace_colour(PROF_DECL const DevScene& S, const Stack& stk, bool active, V3 origin, V3 direction) {
     bool live = active;
     bool in_shadow = false;                 // false: the ray in flight is a segment (primary/reflection) ray; true: a shadow ray
@@ -544,7 +676,7 @@ __device__ __forceinline__ uint32_t trace_colour(PROF_DECL const DevScene& S, co
     while (__any(live)) {
         double t; uint32_t slot;
         PROF_T(4);                                                       // [4] shading / state machine between traversals
-        traverse(PROF_ARG S, stk, live, in_shadow, ro, rd, rmax, t, slot);
+        traverse<kBundle>(PROF_ARG S, stk, live, in_shadow, ro, rd, rmax, t, slot);
         if (live) {
             const bool found = slot != kNone;
             if (!in_shadow) {
@@ -663,6 +795,7 @@ __device__ __forceinline__ uint32_t trace_colour(PROF_DECL const DevScene& S, co
 #ifndef RRT_WAVES_PER_SIMD
 #define RRT_WAVES_PER_SIMD 5   // measured best on MI355X: 96 VGPRs (cold shading state spills to scratch), LDS stack 768 B/level/wave
 #endif
+template <bool kBundle>
 __global__ __launch_bounds__(64, RRT_WAVES_PER_SIMD) void render_kernel(const DevScene S, const FrameParams F, uint32_t* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const uint32_t lane = threadIdx.x;
@@ -688,7 +821,7 @@ __global__ __launch_bounds__(64, RRT_WAVES_PER_SIMD) void render_kernel(const De
 #ifdef RRT_PROFILE
     Prof prof{}; prof.last = __builtin_amdgcn_s_memtime();
 #endif
-    const uint32_t c = trace_colour(PROF_ARG S, stk, traced, ld3(S.origin), dir);
+    const uint32_t c = trace_colour<kBundle>(PROF_ARG S, stk, traced, ld3(S.origin), dir);
 #ifdef RRT_PROFILE
     PROF_T(4);
     if (lane == 0) { for (int i = 0; i < 16; i++) if (prof.c[i]) atomicAdd(S.prof + i, prof.c[i]); for (int i = 0; i < 8; i++) if (prof.t[i]) atomicAdd(S.prof + 16 + i, prof.t[i]); }
@@ -717,6 +850,7 @@ __global__ __launch_bounds__(256) void detile_kernel(uint32_t width, uint32_t he
     fb[i] = gathered[((size_t)r * tiles_per_rank + lt) * 64 + ((py & 7u) * 8 + (px & 7u))];
 }
 
+template <bool kBundle>
 __global__ __launch_bounds__(64) void ray_colour_kernel(const DevScene S, uint32_t n, const double* __restrict__ origins, const double* __restrict__ dirs,
                                                         uint32_t* __restrict__ colours) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -727,10 +861,11 @@ __global__ __launch_bounds__(64) void ray_colour_kernel(const DevScene S, uint32
 #ifdef RRT_PROFILE
     Prof prof{}; prof.last = 0;
 #endif
-    const uint32_t c = trace_colour(PROF_ARG S, stk, ok, o, d);
+    const uint32_t c = trace_colour<kBundle>(PROF_ARG S, stk, ok, o, d);
     if (ok) colours[i] = c;
 }
 
+template <bool kBundle>
 __global__ __launch_bounds__(64) void intersect_kernel(const DevScene S, uint32_t n, const double* __restrict__ origins, const double* __restrict__ dirs,
                                                        const double* __restrict__ max_t, uint8_t* __restrict__ hit, double* __restrict__ t_out,
                                                        double* __restrict__ u_out, double* __restrict__ v_out, uint32_t* __restrict__ tri_out) {
@@ -744,7 +879,7 @@ __global__ __launch_bounds__(64) void intersect_kernel(const DevScene S, uint32_
 #ifdef RRT_PROFILE
     Prof prof{}; prof.last = 0;
 #endif
-    traverse(PROF_ARG S, stk, ok, false, o, d, mt, t, slot);
+    traverse<kBundle>(PROF_ARG S, stk, ok, false, o, d, mt, t, slot);
     if (!ok) return;
     if (slot == kNone) { hit[i] = 0; t_out[i] = 0; u_out[i] = 0; v_out[i] = 0; tri_out[i] = kNone; return; }
     double t2, u = 0, v = 0;
@@ -756,11 +891,12 @@ __global__ __launch_bounds__(64) void intersect_kernel(const DevScene S, uint32_
 
 uint32_t stack_bytes_per_wave(uint32_t levels) { return levels * kLevelBytes; }
 
-int launch_render(const DevScene& s, const FrameParams& f, uint32_t* d_out, void* stream) {
+int launch_render(const DevScene& s, const FrameParams& f, uint32_t* d_out, void* stream, bool bundle) {
     const uint32_t n_tiles = f.tiles_x * f.tiles_y;
     const uint32_t local_tiles = (n_tiles + f.world - 1) / f.world;
     if (local_tiles == 0) return 0;
-    hipLaunchKernelGGL(render_kernel, dim3(local_tiles * 4), dim3(64), stack_bytes_per_wave(s.stack_levels), (hipStream_t)stream, s, f, d_out);
+    if (bundle) hipLaunchKernelGGL(render_kernel<true>, dim3(local_tiles * 4), dim3(64), stack_bytes_per_wave(s.stack_levels), (hipStream_t)stream, s, f, d_out);
+    else hipLaunchKernelGGL(render_kernel<false>, dim3(local_tiles * 4), dim3(64), stack_bytes_per_wave(s.stack_levels), (hipStream_t)stream, s, f, d_out);
     return (int)hipGetLastError();
 }
 
@@ -773,16 +909,19 @@ int launch_detile(uint32_t width, uint32_t height, uint32_t world, const uint32_
     return (int)hipGetLastError();
 }
 
-int launch_ray_colours(const DevScene& s, uint32_t n, const double* d_origins, const double* d_dirs, uint32_t* d_colours, void* stream) {
+int launch_ray_colours(const DevScene& s, uint32_t n, const double* d_origins, const double* d_dirs, uint32_t* d_colours, void* stream, bool bundle) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(ray_colour_kernel, dim3((n + 63) / 64), dim3(64), stack_bytes_per_wave(s.stack_levels), (hipStream_t)stream, s, n, d_origins, d_dirs, d_colours);
+    if (bundle) hipLaunchKernelGGL(ray_colour_kernel<true>, dim3((n + 63) / 64), dim3(64), stack_bytes_per_wave(s.stack_levels), (hipStream_t)stream, s, n, d_origins, d_dirs, d_colours);
+    else hipLaunchKernelGGL(ray_colour_kernel<false>, dim3((n + 63) / 64), dim3(64), stack_bytes_per_wave(s.stack_levels), (hipStream_t)stream, s, n, d_origins, d_dirs, d_colours);
     return (int)hipGetLastError();
 }
 
 int launch_intersect(const DevScene& s, uint32_t n, const double* d_origins, const double* d_dirs, const double* d_max_t,
-                     uint8_t* d_hit, double* d_t, double* d_u, double* d_v, uint32_t* d_tri, void* stream) {
+                     uint8_t* d_hit, double* d_t, double* d_u, double* d_v, uint32_t* d_tri, void* stream, bool bundle) {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(intersect_kernel, dim3((n + 63) / 64), dim3(64), stack_bytes_per_wave(s.stack_levels), (hipStream_t)stream, s, n, d_origins, d_dirs,
+    if (bundle) hipLaunchKernelGGL(intersect_kernel<true>, dim3((n + 63) / 64), dim3(64), stack_bytes_per_wave(s.stack_levels), (hipStream_t)stream, s, n, d_origins, d_dirs,
+                       d_max_t, d_hit, d_t, d_u, d_v, d_tri);
+    else hipLaunchKernelGGL(intersect_kernel<false>, dim3((n + 63) / 64), dim3(64), stack_bytes_per_wave(s.stack_levels), (hipStream_t)stream, s, n, d_origins, d_dirs,
                        d_max_t, d_hit, d_t, d_u, d_v, d_tri);
     return (int)hipGetLastError();
 }

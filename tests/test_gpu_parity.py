@@ -114,14 +114,19 @@ def test_cluster_index_is_result_preserving(rrt, name, w, h):
     order, as ray.rs:119-129): frames must be IDENTICAL, at configs[0]/configs[1] sizes too; likewise t/u/v/triangle of random rays."""
     sd = rrt.parse_obj_file(os.path.join(ASSETS, name))
     fast = rrt.RayTracer(sd, rrt.default_lights()); exact = rrt.RayTracer(sd, rrt.default_lights(), no_cull=True)
-    assert np.array_equal(fast.render(w, h), exact.render(w, h))
+    lane = rrt.RayTracer(sd, rrt.default_lights(), box_filter="lane"); bundle = rrt.RayTracer(sd, rrt.default_lights(), box_filter="bundle")
+    ref = exact.render(w, h)
+    assert np.array_equal(fast.render(w, h), ref) and np.array_equal(lane.render(w, h), ref) and np.array_equal(bundle.render(w, h), ref)
+    assert lane.last_stats()["filter_variant"] == 0 and bundle.last_stats()["filter_variant"] == 1
     rng = np.random.default_rng(11)
     n = 20000
     o = rng.uniform([-5, -0.5, -8], [5, 6, 5], (n, 3)); d = rng.normal(size=(n, 3)); d[:500, rng.integers(0, 3)] = 0.0
     mt = rng.uniform(0.5, 40.0, n); mt[::3] = np.inf
-    a = fast.intersect_rays(o, d, mt); b = exact.intersect_rays(o, d, mt)
-    for x, y in zip(a, b):
-        assert np.array_equal(x, y)
+    b = exact.intersect_rays(o, d, mt)
+    for other in (fast, lane, bundle):                      # incoherent random rays: the bundle's interval test degenerates gracefully
+        for x, y in zip(other.intersect_rays(o, d, mt), b):
+            assert np.array_equal(x, y)
+    assert np.array_equal(bundle.get_ray_colours(o[:4096], d[:4096]), exact.get_ray_colours(o[:4096], d[:4096]))
     big = rrt.RayTracer(sd, rrt.default_lights(), rrt.Vector3d(1e4, 2.0, -10.0))       # origin beyond the fp32 filter's scale limit: filter must switch itself off
     big_exact = rrt.RayTracer(sd, rrt.default_lights(), rrt.Vector3d(1e4, 2.0, -10.0), no_cull=True)
     assert np.array_equal(big.render(64, 48), big_exact.render(64, 48))

@@ -19,6 +19,7 @@ rts = []
 for m in mods:
     sd = m.parse_obj_file(scene)
     rts.append((m, sd, m.RayTracer(sd, m.default_lights())))
+    print(os.path.basename(path), "filter_variant (autotuned):", rts[-1][2].last_stats().get("filter_variant"))
 frames = [rt.render(W, H) for _, _, rt in rts]
 print("frames identical:", all(np.array_equal(frames[0], f) for f in frames[1:]))
 times = [[] for _ in rts]

@@ -13,6 +13,7 @@ for i, path in enumerate(libs):
         syn = importlib.import_module("rust-ray-tracer_amd.synthetic"); path_obj = syn.ensure_soup(os.path.join(ROOT, "assets"), 100000, syn.SEED_100K)
     sd = m.parse_obj_file(path_obj)
     rts.append(m.RayTracer(sd, m.default_lights()))
+    print(os.path.basename(path), "filter_variant (autotuned):", rts[-1].last_stats().get("filter_variant"))
 frames = [rt.render(1920, 1080) for rt in rts]
 print("frames identical:", all(np.array_equal(frames[0], f) for f in frames[1:]))
 times = [[] for _ in rts]
