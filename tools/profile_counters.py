@@ -9,7 +9,7 @@ rrt = importlib.import_module("rust-ray-tracer_amd")
 W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1920, 1080)
 scene = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "assets/model2.obj")
 sd = rrt.parse_obj_file(scene)
-rt = rrt.RayTracer(sd, rrt.default_lights())
+rt = rrt.RayTracer(sd, rrt.default_lights(), box_filter=os.environ.get("RRT_FILTER") or None)
 L = rrt.lib()
 L.rrt_prof_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 buf = (C.c_uint64 * 24)()
