@@ -53,3 +53,16 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle/" not in text.replace("oracle/rrt_oracle", "") or "import" not in text.split("oracle/")[0][-40:], f
                 assert "liboracle" not in text and "from oracle" not in text and "import oracle" not in text, f
+
+
+def test_cpp_host_mirror_builds_and_links(rrt):
+    """The C++ host mirror (csrc/host/rrt_host.hpp + render_cli.cpp, the reference's main.rs over the C ABI) is built by build(); without a GPU
+    it must fail with the library's NO_DEVICE status, not crash."""
+    import subprocess
+    cli = os.path.join(ROOT, "rust-ray-tracer_amd", "render_cli")
+    assert os.path.exists(cli), "render_cli was not built (make -C rust-ray-tracer_amd/csrc)"
+    r = subprocess.run([cli], capture_output=True, text=True)
+    assert r.returncode == 2 and "First argument" in r.stderr                       # main.rs:22-24
+    if rrt.device_count() == 0:
+        r = subprocess.run([cli, os.path.join(ROOT, "assets", "model2.obj"), "/dev/null", "16", "16"], capture_output=True, text=True)
+        assert r.returncode == 1 and "no usable HIP device" in r.stderr, r.stderr
