@@ -2,14 +2,17 @@
 import collections, csv, glob, json, os, sys
 out_dir, tag = sys.argv[1], sys.argv[2]
 summary = {"tag": tag, "kernel": "render_kernel", "pmc_avg_per_launch": {}, "kernel_stats": None}
+dominant = None      # render_kernel<false> (lane filter) and render_kernel<true> (bundle filter) both run while the variant is tuned: keep the one that does the frames
 for f in glob.glob(os.path.join(out_dir, "trace", "*", "*kernel_stats.csv")):
     for r in csv.DictReader(open(f)):
-        if "render_kernel" in r["Name"]:
+        if "render_kernel" in r["Name"] and (dominant is None or int(r["Calls"]) > int(summary["kernel_stats"]["Calls"])):
+            dominant = r["Name"]
             summary["kernel_stats"] = {k: r[k] for k in ("Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")}
+summary["kernel"] = dominant
 for f in glob.glob(os.path.join(out_dir, "pmc_*", "*", "*counter_collection.csv")):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "render_kernel" in r["Kernel_Name"]:
+        if r["Kernel_Name"] == dominant or (dominant is None and "render_kernel" in r["Kernel_Name"]):
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         summary["pmc_avg_per_launch"][k] = sum(v) / len(v)
