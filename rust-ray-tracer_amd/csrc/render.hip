@@ -792,11 +792,17 @@ __device__ __forceinline__ uint32_t trace_colour(PROF_DECL const DevScene& S, co
 
 // ------------------------------------------------------------------------------------------------ kernels
 // One wave per workgroup; workgroup b renders quadrant (b & 3) of this rank's local tile (b >> 2).
-#ifndef RRT_WAVES_PER_SIMD
-#define RRT_WAVES_PER_SIMD 5   // measured best on MI355X: 96 VGPRs (cold shading state spills to scratch), LDS stack 768 B/level/wave
+// Waves per SIMD (register budget) per filter variant, measured on MI355X: the lane-filter kernel runs best at 5 (96 VGPRs; scattered-ray scenes
+// need the latency hiding), the bundle-filter kernel equally fast at 4 and 5 -- 4 (128 VGPRs) spills far less (HBM traffic 1.3 GB vs 4.1 GB per
+// 1080p frame; the shading state that is cold during a walk is what spills).
+#ifndef RRT_WAVES_LANE
+#define RRT_WAVES_LANE 5
+#endif
+#ifndef RRT_WAVES_BUNDLE
+#define RRT_WAVES_BUNDLE 4
 #endif
 template <bool kBundle>
-__global__ __launch_bounds__(64, RRT_WAVES_PER_SIMD) void render_kernel(const DevScene S, const FrameParams F, uint32_t* __restrict__ out) {
+__global__ __launch_bounds__(64, kBundle ? RRT_WAVES_BUNDLE : RRT_WAVES_LANE) void render_kernel(const DevScene S, const FrameParams F, uint32_t* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const uint32_t lane = threadIdx.x;
     const Stack stk{lds, lane};
