@@ -6,8 +6,8 @@
 
 A step = one full frame of the scene (Scene::draw_scene, engine.rs:186-255) with the scene already resident in HBM and the
 framebuffer left in HBM.  N = 1: one launch of the trace kernel writes the row-major framebuffer.  N > 1: the frame's 8x8-pixel
-tiles are dealt round-robin to the ranks (tile k -> rank k % N), each rank traces its tiles, one RCCL all-gather over xGMI
-collects the tile-major buffers and every rank de-tiles to the row-major frame ("scaling": "strong" -- the frame is fixed).
+tiles are dealt round-robin to the ranks (tile k -> rank k % N), each rank traces its tiles, one RCCL gather over xGMI
+collects the tile-major buffers on GPU 0, which de-tiles them to the row-major frame ("scaling": "strong" -- the frame is fixed).
 Rank 0 prints ONE JSON line.  The `roofline` object prices the trace kernel against the f64 VECTOR peak (this path is VALU-bound:
 no MFMA, almost no HBM traffic -- see DESIGN.md section 5) and carries the HBM figure the metric asks for as `hbm`.
 `cpu_baseline` is the oracle (restatement of the reference's rayon CPU path; the Rust reference cannot be built here) timed on
@@ -79,6 +79,8 @@ def main() -> None:
         tpr = rrt.tiles_per_rank(W, H, world)
         mine = torch.zeros(tpr * 64, dtype=torch.int32, device="cuda")
         gathered = torch.zeros(world * tpr * 64, dtype=torch.int32, device="cuda")
+        # final gather to GPU 0 (BASELINE.json north_star): grouped point-to-point sends, every peer on its own xGMI link -- not a ring
+        chunks = [gathered[i * tpr * 64:(i + 1) * tpr * 64] for i in range(world)] if rank == 0 else None
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
@@ -91,8 +93,9 @@ def main() -> None:
             if i is not None: ev[i][0].record()
             rt.render_tiles_into(mine, W, H, rank, world)
             if i is not None: ev[i][1].record()
-            dist.all_gather_into_tensor(gathered, mine)
-            rt.detile_into(gathered, fb, W, H, world)
+            dist.gather(mine, chunks, dst=0)
+            if rank == 0:
+                rt.detile_into(gathered, fb, W, H, world)
 
     def fence() -> None:
         if world > 1:
@@ -211,7 +214,7 @@ def main() -> None:
                "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "reference scene assets/model2.obj (teapot+table+mirror, 6334 triangles), camera/lights of main.rs"
                if os.path.basename(args.scene) == "model2.obj" else "synthetic",
                "config": {"workload": f"{os.path.basename(args.scene)} {W}x{H}, 4 sub-samples/pixel, shadow rays + depth-5 mirror reflection, f64",
-                          "rays_primary_per_frame": rays_primary, "partition": "single launch" if world == 1 else f"8x8-pixel tiles round-robin over {world} GPUs + RCCL all-gather",
+                          "rays_primary_per_frame": rays_primary, "partition": "single launch" if world == 1 else f"8x8-pixel tiles round-robin over {world} GPUs + RCCL gather to GPU 0",
                           "octree_nodes": sd.info["n_nodes"], "triangles": sd.info["n_tris"]},
                "frame_ms": round(ms_per_step, 4), "kernel_ms": round(kernel_ms, 4), **({"rehearsal": "gloo on one GPU: NOT a benchmark result"} if rehearsal else {}),
                "frame_checksum": int(np.bitwise_xor.reduce(frame.ravel().astype(np.uint64) * np.arange(1, frame.size + 1, dtype=np.uint64)))}

@@ -132,7 +132,7 @@ int rrt_render_device(rrt_raytracer *rt, uint32_t width, uint32_t height, void *
 
 /* Screen-tile partition for N GPUs (one process per GPU): the frame is cut into 8x8-pixel tiles, tile k (row-major)
  * belongs to rank k % world.  Renders this rank's tiles into d_tiles[rrt_tiles_per_rank][64] (tile-major, device).
- * After an all-gather of the per-rank buffers (RCCL, done by the caller), rrt_detile_device turns
+ * After a gather (or all-gather) of the per-rank buffers (RCCL, done by the caller), rrt_detile_device turns
  * d_gathered[world][tiles_per_rank][64] into the row-major framebuffer d_fb[width*height]. */
 uint32_t rrt_tiles_per_rank(uint32_t width, uint32_t height, uint32_t world);
 int rrt_render_tiles_device(rrt_raytracer *rt, uint32_t width, uint32_t height, uint32_t rank, uint32_t world,

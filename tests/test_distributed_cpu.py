@@ -1,8 +1,8 @@
 """N>1 path on CPU: the screen-tile partition, the gather layout and the de-tiling, with torch.distributed gloo, world_size 2.
 
 No GPU here, so each rank fills its tile-major buffer from a frame rendered by the ORACLE (checker) with the same host-side
-partition function the kernel uses (tile k -> rank k % world, 8x8 pixels, tile-major [tiles_per_rank][64]); the ranks all-gather the
-buffers exactly as bench.py does over RCCL, and the de-tiled result must be the original frame on every rank."""
+partition function the kernel uses (tile k -> rank k % world, 8x8 pixels, tile-major [tiles_per_rank][64]); the ranks gather the
+buffers to rank 0 exactly as bench.py does over RCCL, and the de-tiled result must be the original frame."""
 import os
 import sys
 
@@ -36,9 +36,11 @@ def _worker(rank, world, port, w, h, frame_path, out_dir):
     frame = np.load(frame_path)
     mine = torch.from_numpy(_tile_major(frame, world, rank, rrt).view(np.int32).copy()).reshape(-1)
     gathered = torch.empty(world * mine.numel(), dtype=torch.int32)
-    dist.all_gather_into_tensor(gathered, mine)
-    fb = rrt.detile_host(gathered.numpy().view(np.uint32), w, h, world)
-    np.save(os.path.join(out_dir, f"fb_{rank}.npy"), fb)
+    chunks = [gathered[i * mine.numel():(i + 1) * mine.numel()] for i in range(world)] if rank == 0 else None
+    dist.gather(mine, chunks, dst=0)                       # as bench.py: final gather to rank 0, which de-tiles
+    if rank == 0:
+        fb = rrt.detile_host(gathered.numpy().view(np.uint32), w, h, world)
+        np.save(os.path.join(out_dir, "fb_0.npy"), fb)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -50,8 +52,7 @@ def test_tile_partition_allgather_gloo_world2(rrt, teapot_oracle, tmp_path, w, h
     world = 2
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(world, port, w, h, str(tmp_path / "frame.npy"), str(tmp_path)), nprocs=world, join=True)
-    for r in range(world):
-        assert np.array_equal(np.load(tmp_path / f"fb_{r}.npy"), frame), r
+    assert np.array_equal(np.load(tmp_path / "fb_0.npy"), frame)
 
 
 def test_partition_is_balanced_and_complete(rrt):
