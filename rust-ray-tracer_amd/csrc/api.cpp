@@ -24,6 +24,8 @@ struct rrt_raytracer {
     bool stats_pending = false;
     bool bundle = false;             // own-list filter variant used by this raytracer's launches (see rrt.h)
     bool variant_forced = false;
+    void* host_fb = nullptr;         // device framebuffer kept between rrt_render calls (host-buffer entry point)
+    size_t host_fb_bytes = 0;
     uint32_t tuned_w = 0, tuned_h = 0, tuned_world = 0;
 };
 
@@ -386,6 +388,7 @@ void rrt_raytracer_destroy(rrt_raytracer* rt) {
     if (hipGetDevice(&prev) == hipSuccess) {
         (void)hipSetDevice(rt->device);
         for (void* p : rt->allocs) (void)hipFree(p);
+        if (rt->host_fb) (void)hipFree(rt->host_fb);
         if (rt->ev0) (void)hipEventDestroy(rt->ev0);
         if (rt->ev1) (void)hipEventDestroy(rt->ev1);
         (void)hipSetDevice(prev);
@@ -445,13 +448,14 @@ int rrt_render(rrt_raytracer* rt, uint32_t width, uint32_t height, uint32_t* out
         if (!out_fb) throw Error{RRT_ERR_INVALID_ARG, "null framebuffer"};
         DeviceGuard guard(rt->device);
         const size_t bytes = sizeof(uint32_t) * (size_t)width * height;
-        void* d = nullptr;
-        HIP_TRY(hipMalloc(&d, bytes));
-        int rc = rrt_render_device(rt, width, height, d, nullptr);
-        hipError_t e = rc == RRT_OK ? hipMemcpy(out_fb, d, bytes, hipMemcpyDeviceToHost) : hipSuccess;
-        (void)hipFree(d);
+        if (rt->host_fb_bytes < bytes) {                                   // the device-side frame is kept and reused from call to call
+            if (rt->host_fb) { (void)hipFree(rt->host_fb); rt->host_fb = nullptr; rt->host_fb_bytes = 0; }
+            HIP_TRY(hipMalloc(&rt->host_fb, bytes));
+            rt->host_fb_bytes = bytes;
+        }
+        const int rc = rrt_render_device(rt, width, height, rt->host_fb, nullptr);
         if (rc != RRT_OK) return rc;
-        HIP_TRY(e);
+        HIP_TRY(hipMemcpy(out_fb, rt->host_fb, bytes, hipMemcpyDeviceToHost));   // blocking: the frame is in out_fb on return
         return RRT_OK;
     });
 }
