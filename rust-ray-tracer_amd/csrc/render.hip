@@ -247,26 +247,39 @@ struct Prof { unsigned long long c[16]; unsigned long long t[8]; unsigned long l
 #endif
 
 // ------------------------------------------------------------------------------------------------ traversal
-// minimum of v over the 64 lanes (DPP row shifts + row broadcasts, result read from lane 63)
+// Wave reductions with in-place DPP: `v_min_* v, v, v row_shr:k` -- a lane whose DPP source is out of range keeps its own value, so six steps
+// (row_shr 1,2,4,8, row_bcast 15,31) leave the reduction of all 64 lanes in lane 63.  hipcc's own lowering of the same pattern spends four
+// instructions per step (identity move, DPP move, NaN-canonicalise, min).  Inline asm gets no automatic wait states (cdna guide 5.7): a VALU
+// write followed by a DPP read of the same VGPR needs 2, hence the s_nop 1 between dependent steps.
+#define RRT_DPP_STEP_U32(v, ctrl) asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 " ctrl : "+v"(v))
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-    const int id = -1;   // identity of min for lanes a DPP step does not feed
-    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x111, 0xf, 0xf, false));   // row_shr:1
-    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x112, 0xf, 0xf, false));   // row_shr:2
-    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x114, 0xf, 0xf, false));   // row_shr:4
-    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x118, 0xf, 0xf, false));   // row_shr:8
-    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x142, 0xa, 0xf, false));   // row_bcast:15
-    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(id, (int)v, 0x143, 0xc, 0xf, false));   // row_bcast:31
+    RRT_DPP_STEP_U32(v, "row_shr:1 row_mask:0xf bank_mask:0xf");
+    RRT_DPP_STEP_U32(v, "row_shr:2 row_mask:0xf bank_mask:0xf");
+    RRT_DPP_STEP_U32(v, "row_shr:4 row_mask:0xf bank_mask:0xf");
+    RRT_DPP_STEP_U32(v, "row_shr:8 row_mask:0xf bank_mask:0xf");
+    RRT_DPP_STEP_U32(v, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+    RRT_DPP_STEP_U32(v, "row_bcast:31 row_mask:0xc bank_mask:0xf");
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
-
-__device__ __forceinline__ float wave_min_f32(float v) {
-    const int id = 0x7F800000;   // +inf
-#define RRT_STEP(ctrl, rm) v = fminf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(id, __builtin_bit_cast(int, v), ctrl, rm, 0xf, false)))
-    RRT_STEP(0x111, 0xf); RRT_STEP(0x112, 0xf); RRT_STEP(0x114, 0xf); RRT_STEP(0x118, 0xf); RRT_STEP(0x142, 0xa); RRT_STEP(0x143, 0xc);
-#undef RRT_STEP
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+// Twelve f32 min-reductions at once, step by step across all twelve registers: dependent DPP operations are then 12 instructions apart and need
+// no wait states (only the first step follows ordinary VALU writes).  All inputs are finite or +-inf, never NaN.
+#define RRT_DPP12(ctrl)                                                                                              \
+    asm volatile("v_min_f32_dpp %0, %0, %0 " ctrl "\n\tv_min_f32_dpp %1, %1, %1 " ctrl "\n\tv_min_f32_dpp %2, %2, %2 " ctrl "\n\t"    \
+                 "v_min_f32_dpp %3, %3, %3 " ctrl "\n\tv_min_f32_dpp %4, %4, %4 " ctrl "\n\tv_min_f32_dpp %5, %5, %5 " ctrl "\n\t"    \
+                 "v_min_f32_dpp %6, %6, %6 " ctrl "\n\tv_min_f32_dpp %7, %7, %7 " ctrl "\n\tv_min_f32_dpp %8, %8, %8 " ctrl "\n\t"    \
+                 "v_min_f32_dpp %9, %9, %9 " ctrl "\n\tv_min_f32_dpp %10, %10, %10 " ctrl "\n\tv_min_f32_dpp %11, %11, %11 " ctrl     \
+                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]))
+__device__ __forceinline__ void wave_min12_f32(float (&x)[12]) {
+    asm volatile("s_nop 1" ::: "memory");
+    RRT_DPP12("row_shr:1 row_mask:0xf bank_mask:0xf");
+    RRT_DPP12("row_shr:2 row_mask:0xf bank_mask:0xf");
+    RRT_DPP12("row_shr:4 row_mask:0xf bank_mask:0xf");
+    RRT_DPP12("row_shr:8 row_mask:0xf bank_mask:0xf");
+    RRT_DPP12("row_bcast:15 row_mask:0xa bank_mask:0xf");
+    RRT_DPP12("row_bcast:31 row_mask:0xc bank_mask:0xf");
+#pragma unroll
+    for (int i = 0; i < 12; i++) x[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x[i]), 63));
 }
-__device__ __forceinline__ float wave_max_f32(float v) { return -wave_min_f32(-v); }
 
 // ---- the wave's ray bundle, for the boxes-in-lanes filter (RRT_BUNDLE).  A slab value of lane l is a_l(b) = b*inv_l - o_l*inv_l
 // = (b - c)*inv_l + m_l with m_l = (c - o_l)*inv_l and c a common reference point (the first active lane's origin: m_l = 0 for a bundle
@@ -283,12 +296,12 @@ __device__ __forceinline__ Bundle make_bundle(bool active, V3 o, const Ray32& r)
     B.cz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, oz), leader));
     const float mx = (B.cx - ox) * r.ix, my = (B.cy - oy) * r.iy, mz = (B.cz - oz) * r.iz;
     const float pinf = __builtin_huge_valf();
-    B.ilx = wave_min_f32(active ? r.ix : pinf); B.ihx = wave_max_f32(active ? r.ix : -pinf);
-    B.ily = wave_min_f32(active ? r.iy : pinf); B.ihy = wave_max_f32(active ? r.iy : -pinf);
-    B.ilz = wave_min_f32(active ? r.iz : pinf); B.ihz = wave_max_f32(active ? r.iz : -pinf);
-    B.mlx = wave_min_f32(active ? mx : pinf); B.mhx = wave_max_f32(active ? mx : -pinf);
-    B.mly = wave_min_f32(active ? my : pinf); B.mhy = wave_max_f32(active ? my : -pinf);
-    B.mlz = wave_min_f32(active ? mz : pinf); B.mhz = wave_max_f32(active ? mz : -pinf);
+    // min over the active lanes of x and of -x (max = -min(-x)); inactive lanes hold +inf
+    float x[12] = {active ? r.ix : pinf, active ? -r.ix : pinf, active ? r.iy : pinf, active ? -r.iy : pinf, active ? r.iz : pinf, active ? -r.iz : pinf,
+                   active ? mx : pinf,   active ? -mx : pinf,   active ? my : pinf,   active ? -my : pinf,   active ? mz : pinf,   active ? -mz : pinf};
+    wave_min12_f32(x);
+    B.ilx = x[0]; B.ihx = -x[1]; B.ily = x[2]; B.ihy = -x[3]; B.ilz = x[4]; B.ihz = -x[5];
+    B.mlx = x[6]; B.mhx = -x[7]; B.mly = x[8]; B.mhy = -x[9]; B.mlz = x[10]; B.mhz = -x[11];
     // an axis whose directions have mixed signs in the wave gives no bound; a lane with the filter off (inv = 0) switches the bundle test off
     B.ubx = B.ilx < 0.0f && B.ihx > 0.0f; B.uby = B.ily < 0.0f && B.ihy > 0.0f; B.ubz = B.ilz < 0.0f && B.ihz > 0.0f;
     B.off = act == 0ull || __builtin_amdgcn_ballot_w64(active && r.ix == 0.0f && r.iy == 0.0f && r.iz == 0.0f) != 0ull;
