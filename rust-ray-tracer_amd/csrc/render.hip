@@ -285,7 +285,7 @@ __device__ __forceinline__ void wave_min12_f32(float (&x)[12]) {
 // = (b - c)*inv_l + m_l with m_l = (c - o_l)*inv_l and c a common reference point (the first active lane's origin: m_l = 0 for a bundle
 // with one origin).  With inv_l in [imin, imax] (same sign) and m_l in [mmin, mmax], a_l(b) lies in (b-c)*[imin,imax] + [mmin,mmax]: an
 // interval that bounds every lane's near/far slab values, so a box whose interval test fails is missed by every lane's own test.
-struct Bundle { float cx, cy, cz, ilx, ihx, ily, ihy, ilz, ihz, mlx, mhx, mly, mhy, mlz, mhz; bool off, ubx, uby, ubz; };
+struct Bundle { float cx, cy, cz, ilx, ihx, ily, ihy, ilz, ihz, mlx, mhx, mly, mhy, mlz, mhz; };
 __device__ __forceinline__ Bundle make_bundle(bool active, V3 o, const Ray32& r) {
     Bundle B;
     const unsigned long long act = __builtin_amdgcn_ballot_w64(active);
@@ -302,26 +302,33 @@ __device__ __forceinline__ Bundle make_bundle(bool active, V3 o, const Ray32& r)
     wave_min12_f32(x);
     B.ilx = x[0]; B.ihx = -x[1]; B.ily = x[2]; B.ihy = -x[3]; B.ilz = x[4]; B.ihz = -x[5];
     B.mlx = x[6]; B.mhx = -x[7]; B.mly = x[8]; B.mhy = -x[9]; B.mlz = x[10]; B.mhz = -x[11];
-    // an axis whose directions have mixed signs in the wave gives no bound; a lane with the filter off (inv = 0) switches the bundle test off
-    B.ubx = B.ilx < 0.0f && B.ihx > 0.0f; B.uby = B.ily < 0.0f && B.ihy > 0.0f; B.ubz = B.ilz < 0.0f && B.ihz > 0.0f;
-    B.off = act == 0ull || __builtin_amdgcn_ballot_w64(active && r.ix == 0.0f && r.iy == 0.0f && r.iz == 0.0f) != 0ull;
+    // An axis whose directions have mixed signs in the wave gives no bound: its inv interval becomes [-FLT_MAX, FLT_MAX], whose products are
+    // -inf/+inf (or 0 for a plane through c) -- no constraint, no NaN.  A lane with the filter off (inv = 0) switches the whole bundle test
+    // off: all-zero intervals make every slab value 0 and every box a hit.
+    constexpr float kBig = 3.0e38f;
+    if (B.ilx < 0.0f && B.ihx > 0.0f) { B.ilx = -kBig; B.ihx = kBig; }
+    if (B.ily < 0.0f && B.ihy > 0.0f) { B.ily = -kBig; B.ihy = kBig; }
+    if (B.ilz < 0.0f && B.ihz > 0.0f) { B.ilz = -kBig; B.ihz = kBig; }
+    if (act == 0ull || __builtin_amdgcn_ballot_w64(active && r.ix == 0.0f && r.iy == 0.0f && r.iz == 0.0f) != 0ull) {
+        B.ilx = B.ihx = B.ily = B.ihy = B.ilz = B.ihz = 0.0f; B.mlx = B.mhx = B.mly = B.mhy = B.mlz = B.mhz = 0.0f;
+    }
     return B;
 }
 // per-LANE box (lo/hi in VGPRs) against the bundle: false only if no active lane's own slab test could pass
 __device__ __forceinline__ bool bundle_hit(const Bundle& B, float lox, float loy, float loz, float hix, float hiy, float hiz) {
-    float tn = 0.0f, tf = __builtin_huge_valf();
-#define RRT_AX(lo, hi, c, il, ih, ml, mh, ub)                                                                  \
-    if (!ub) {                                                                                                  \
+#define RRT_AX(lo, hi, c, il, ih, ml, mh, tn, tf)                                                              \
+    float tn, tf;                                                                                               \
+    {                                                                                                           \
         const float pl = lo - c, ph = hi - c;                                                                   \
         const float a1 = pl * il, a2 = pl * ih, b1 = ph * il, b2 = ph * ih;                                     \
-        tn = fmaxf(tn, fminf(fminf(a1, a2), fminf(b1, b2)) + ml);                                               \
-        tf = fminf(tf, fmaxf(fmaxf(a1, a2), fmaxf(b1, b2)) + mh);                                               \
+        tn = fminf(fminf(a1, a2), fminf(b1, b2)) + ml;                                                          \
+        tf = fmaxf(fmaxf(a1, a2), fmaxf(b1, b2)) + mh;                                                          \
     }
-    RRT_AX(lox, hix, B.cx, B.ilx, B.ihx, B.mlx, B.mhx, B.ubx)
-    RRT_AX(loy, hiy, B.cy, B.ily, B.ihy, B.mly, B.mhy, B.uby)
-    RRT_AX(loz, hiz, B.cz, B.ilz, B.ihz, B.mlz, B.mhz, B.ubz)
+    RRT_AX(lox, hix, B.cx, B.ilx, B.ihx, B.mlx, B.mhx, tnx, tfx)
+    RRT_AX(loy, hiy, B.cy, B.ily, B.ihy, B.mly, B.mhy, tny, tfy)
+    RRT_AX(loz, hiz, B.cz, B.ilz, B.ihz, B.mlz, B.mhz, tnz, tfz)
 #undef RRT_AX
-    return B.off || tn <= tf;
+    return fmaxf(fmaxf(fmaxf(tnx, tny), tnz), 0.0f) <= fminf(fminf(tfx, tfy), tfz);
 }
 // stream compaction across the wave (all 64 lanes must execute it): entry k of the survivors ends up in lane k; returns their number
 __device__ __forceinline__ uint32_t wave_compact2(bool keep, uint32_t a, uint32_t b, uint32_t lane, uint32_t& out_a, uint32_t& out_b) {
