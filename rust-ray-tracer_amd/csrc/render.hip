@@ -433,18 +433,25 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                             }
                         }
                     }
-                    // stable ascending sort by t (ray.rs:146-147) as a rank computation over the non-empty children only
+                    // stable ascending sort by t (ray.rs:146-147).  With a single candidate child (the usual case after the reach filter) there is
+                    // nothing to sort; otherwise a rank computation over the candidates only.
+                    if ((reach & (reach - 1u)) == 0u) {
+                        const bool any = vk[0] | vk[1] | vk[2] | vk[3] | vk[4] | vk[5] | vk[6] | vk[7];   // only the candidate's flag can be set
+                        order = reach ? (uint32_t)__builtin_ctz(reach) : 0u;
+                        nchild = any ? 1u : 0u;
+                    } else {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        if (!(reach & (1u << k))) continue;
-                        uint32_t rank = 0;
+                        for (int k = 0; k < 8; ++k) {
+                            if (!(reach & (1u << k))) continue;
+                            uint32_t rank = 0;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            if (j == k || !(reach & (1u << j))) continue;
-                            const bool before = (j < k) ? (tk[j] <= tk[k]) : (tk[j] < tk[k]);
-                            rank += (vk[j] && before) ? 1u : 0u;
+                            for (int j = 0; j < 8; ++j) {
+                                if (j == k || !(reach & (1u << j))) continue;
+                                const bool before = (j < k) ? (tk[j] <= tk[k]) : (tk[j] < tk[k]);
+                                rank += (vk[j] && before) ? 1u : 0u;
+                            }
+                            if (vk[k]) { order |= (uint32_t)k << (3u * rank); nchild++; }
                         }
-                        if (vk[k]) { order |= (uint32_t)k << (3u * rank); nchild++; }
                     }
                 }
             }
