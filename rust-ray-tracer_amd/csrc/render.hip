@@ -216,9 +216,10 @@ __device__ __forceinline__ Ray32 make_ray32(V3 o, V3 d, float limit, bool enable
     const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z, dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
     Ray32 r;
     const bool cull = enabled && fabsf(ox) < limit && fabsf(oy) < limit && fabsf(oz) < limit && fabsf(dx) < limit && fabsf(dy) < limit && fabsf(dz) < limit;
-    r.ix = !cull ? 0.0f : fabsf(dx) < 1e-20f ? 1e30f : 1.0f / dx;
-    r.iy = !cull ? 0.0f : fabsf(dy) < 1e-20f ? 1e30f : 1.0f / dy;
-    r.iz = !cull ? 0.0f : fabsf(dz) < 1e-20f ? 1e30f : 1.0f / dz;
+    // v_rcp_f32 (1 ulp) is plenty for a filter whose boxes are padded by ~1e-5 of the scene: an IEEE divide would cost ten instructions each
+    r.ix = !cull ? 0.0f : fabsf(dx) < 1e-20f ? 1e30f : __builtin_amdgcn_rcpf(dx);
+    r.iy = !cull ? 0.0f : fabsf(dy) < 1e-20f ? 1e30f : __builtin_amdgcn_rcpf(dy);
+    r.iz = !cull ? 0.0f : fabsf(dz) < 1e-20f ? 1e30f : __builtin_amdgcn_rcpf(dz);
     r.nx = !cull ? 0.0f : -ox * r.ix; r.ny = !cull ? 0.0f : -oy * r.iy; r.nz = !cull ? 0.0f : -oz * r.iz;
     return r;
 }
