@@ -321,6 +321,39 @@ class RayTracer:
         _check(lib().rrt_detile_device(self._h, width, height, world, _P(gathered_tensor.data_ptr()), _P(fb_tensor.data_ptr()), _P(_stream(stream))),
                "rrt_detile_device")
 
+    # pre-bound launchers for per-frame loops (bench.py): all argument conversion is done once, the returned callable is one ctypes call
+    def bind_render(self, fb_tensor, width: int, height: int, stream: Optional[int] = None):
+        assert fb_tensor.is_cuda and fb_tensor.is_contiguous() and fb_tensor.numel() == width * height and fb_tensor.element_size() == 4
+        fn, h, w_, h_, p, st = lib().rrt_render_device, self._h, C.c_uint32(width), C.c_uint32(height), _P(fb_tensor.data_ptr()), _P(_stream(stream))
+
+        def launch():
+            rc = fn(h, w_, h_, p, st)
+            if rc != OK:
+                _check(rc, "rrt_render_device")
+        return launch
+
+    def bind_render_tiles(self, tiles_tensor, width: int, height: int, rank: int, world: int, stream: Optional[int] = None):
+        assert tiles_tensor.is_cuda and tiles_tensor.is_contiguous() and tiles_tensor.numel() == tiles_per_rank(width, height, world) * 64
+        fn, h, st = lib().rrt_render_tiles_device, self._h, _P(_stream(stream))
+        args = (C.c_uint32(width), C.c_uint32(height), C.c_uint32(rank), C.c_uint32(world), _P(tiles_tensor.data_ptr()))
+
+        def launch():
+            rc = fn(h, *args, st)
+            if rc != OK:
+                _check(rc, "rrt_render_tiles_device")
+        return launch
+
+    def bind_detile(self, gathered_tensor, fb_tensor, width: int, height: int, world: int, stream: Optional[int] = None):
+        assert gathered_tensor.numel() == tiles_per_rank(width, height, world) * 64 * world and fb_tensor.numel() == width * height
+        fn, h, st = lib().rrt_detile_device, self._h, _P(_stream(stream))
+        args = (C.c_uint32(width), C.c_uint32(height), C.c_uint32(world), _P(gathered_tensor.data_ptr()), _P(fb_tensor.data_ptr()))
+
+        def launch():
+            rc = fn(h, *args, st)
+            if rc != OK:
+                _check(rc, "rrt_detile_device")
+        return launch
+
     def last_stats(self) -> dict:
         s = CStats()
         _check(lib().rrt_last_stats(self._h, C.byref(s)), "rrt_last_stats")
