@@ -695,9 +695,9 @@ __device__ __forceinline__ uint32_t trace_colour(PROF_DECL const DevScene& S, co
     bool in_shadow = false;                 // false: the ray in flight is a segment (primary/reflection) ray; true: a shadow ray
     V3 ro = origin, rd = direction; double rmax = kInf;
     V3 seg_d = direction;
-    V3 p = mk(0, 0, 0), n = mk(0, 0, 0), I = mk(0, 0, 0);
-    double len_n = 0, len_v = 0;
+    V3 p = mk(0, 0, 0), n = mk(0, 0, 0);
     uint32_t col = 0, mat = 0, li = 0, depth = 0;
+    uint32_t n_eval = 0;                    // lights [0, n_eval) contribute (an occluded point light ends the loop, raytracer.rs:235-237)
     uint32_t term = 0x00FFFFFFu;            // colour of the last segment
     double st_local[RRT_MAX_REFLECT][3]; double st_kr[RRT_MAX_REFLECT];
 
@@ -744,51 +744,55 @@ __device__ __forceinline__ uint32_t trace_colour(PROF_DECL const DevScene& S, co
                         nn = mk(dot(bv, tg), dot(bv, bt), dot(bv, nn));                  // raytracer.rs:154-158
                     }
                     n = normalised(nn);                                                  // raytracer.rs:161
-                    len_n = length(n); len_v = length(rd);                               // |normal|, |v| = |-direction| for the light loop
-                    I = mk(0.0, 0.0, 0.0); li = 0;                                       // compute_lighting_intensity, raytracer.rs:199-203
+                    li = 0;                                                              // compute_lighting_intensity, raytracer.rs:199-203
 #ifdef RRT_ABL_NOLIGHTS  /* ablation build only: primary hit set-up, then stop */
-                    li = S.n_lights; I = mk(1.0, 1.0, 1.0);
+                    li = S.n_lights;
 #endif
                 }
             } else {
-                // --- result of the shadow ray for point light li, raytracer.rs:232-252
-                if (found) {
-                    li = S.n_lights;                                                     // `break` leaves the whole light loop, raytracer.rs:235-237
-                } else {
-                    const DevMaterial& M = S.mats[mat];
-                    const DevLight& L = S.lights[li];
-                    const V3 l = ld3(L.v) - p;
-                    const double n_dot_l = dot(n, l);
-                    I = I + diffuse_term(L.intensity, n_dot_l, len_n, rmax, ld3(M.kd));       // rmax = |position - point| from the shadow-ray set-up
-                    I = I + specular_term(M.ns, L.intensity, n, neg(seg_d), len_v, l, ld3(M.ks));
-                    li++;
-                }
+                // --- result of the shadow ray for point light li (raytracer.rs:232-237): occluded -> `break` out of the whole light loop
+                if (found) { n_eval = li; li = 0xFFFFu; }                                // every point light below n_eval was tested and is lit
+                else li++;
                 in_shadow = false;
             }
             if (live) {
-                // --- continue the light loop (raytracer.rs:205-255) up to the next point light
-                const DevMaterial& M = S.mats[mat];
+                // --- walk the light list (raytracer.rs:205-255) up to the next point light, whose shadow ray (raytracer.rs:164-188) is traced next.
+                // The lighting sum itself is formed once all shadow rays of this hit are known (same lights, same order, same additions): the
+                // walks then carry only p, n and the segment direction, not the running intensity.
                 while (li < S.n_lights && !in_shadow) {
                     const DevLight& L = S.lights[li];
-                    if (L.kind == 0u) {                                                  // Ambient, raytracer.rs:207-209
-                        I = I + ld3(M.ka) * L.intensity;
-                        li++;
-                    } else if (L.kind == 2u) {                                           // Directional, raytracer.rs:210-227
-                        const V3 dir = ld3(L.v);
-                        const double n_dot_l = dot(n, dir);
-                        I = I + diffuse_term(L.intensity, n_dot_l, len_n, length(dir), ld3(M.kd));
-                        I = I + specular_term(M.ns, L.intensity, n, neg(seg_d), len_v, dir, ld3(M.ks));
-                        li++;
-                    } else {                                                             // Point -> shadow ray, raytracer.rs:164-188
+                    if (L.kind == 1u) {
                         const V3 dir = ld3(L.v) - p;
                         ro = p + n * S.surface_offset;
                         rd = dir;
                         rmax = length(dir);
                         in_shadow = true;
+                    } else {
+                        li++;
                     }
                 }
                 if (!in_shadow) {
-                    // --- lights done: raytracer.rs:67-108
+                    if (li != 0xFFFFu) n_eval = S.n_lights;
+                    // --- compute_lighting_intensity, raytracer.rs:192-258
+                    const DevMaterial& M = S.mats[mat];
+                    const V3 vdir = neg(seg_d);
+                    const double len_n = length(n), len_v = length(vdir);                // |normal|, |v|: the reference recomputes them per light, same value
+                    V3 I = mk(0.0, 0.0, 0.0);
+#ifdef RRT_ABL_NOLIGHTS
+                    I = mk(1.0, 1.0, 1.0); n_eval = 0;
+#endif
+                    for (uint32_t k = 0; k < n_eval; ++k) {
+                        const DevLight& L = S.lights[k];
+                        if (L.kind == 0u) {                                              // Ambient, raytracer.rs:207-209
+                            I = I + ld3(M.ka) * L.intensity;
+                        } else {                                                         // Directional (raytracer.rs:210-227) / unoccluded Point (raytracer.rs:239-252)
+                            const V3 l = (L.kind == 2u) ? ld3(L.v) : ld3(L.v) - p;
+                            const double n_dot_l = dot(n, l);
+                            I = I + diffuse_term(L.intensity, n_dot_l, len_n, length(l), ld3(M.kd));
+                            I = I + specular_term(M.ns, L.intensity, n, vdir, len_v, l, ld3(M.ks));
+                        }
+                    }
+                    // --- raytracer.rs:67-108
                     const V3 local = mk((double)((col >> 16) & 255u) * I.x, (double)((col >> 8) & 255u) * I.y, (double)(col & 255u) * I.z);
                     const double kr = M.kr;
                     if (kr > 0.0 && depth < S.max_reflection_depth) {                    // raytracer.rs:76
