@@ -412,35 +412,45 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                     // (ray.rs:22-27) is formed ONCE per plane that some reachable child uses (6..9 IEEE divides per node instead of 6 per
                     // child), with the reference's operands, and each child's test is then the reference's min/max on those quotients.
                     // child k = BBL,BFL,BFR,BBR,TBL,TFL,TFR,TBR (octree.rs:216-225): upper x half for k in {2,3,6,7}, y {4..7}, z {1,2,5,6}
-                    double qlx = 0, qmx = 0, qhx = 0, qly = 0, qmy = 0, qhy = 0, qlz = 0, qmz = 0, qhz = 0;
-                    if (reach & 0xFFu) { qmx = (N.mid[0] - o.x) / d.x; qmy = (N.mid[1] - o.y) / d.y; qmz = (N.mid[2] - o.z) / d.z; }
-                    if (reach & 0x33u) qlx = (N.lo[0] - o.x) / d.x;
-                    if (reach & 0xCCu) qhx = (N.hi[0] - o.x) / d.x;
-                    if (reach & 0x0Fu) qly = (N.lo[1] - o.y) / d.y;
-                    if (reach & 0xF0u) qhy = (N.hi[1] - o.y) / d.y;
-                    if (reach & 0x99u) qlz = (N.lo[2] - o.z) / d.z;
-                    if (reach & 0x66u) qhz = (N.hi[2] - o.z) / d.z;
-                    double tk[8]; bool vk[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        vk[k] = false; tk[k] = kInf;
-                        if (reach & (1u << k)) {
-                            constexpr int hx[8] = {0, 0, 1, 1, 0, 0, 1, 1}, hy[8] = {0, 0, 0, 0, 1, 1, 1, 1}, hz[8] = {0, 1, 1, 0, 0, 1, 1, 0};
+                    if ((reach & (reach - 1u)) == 0u) {
+                        // a single candidate child (the usual case after the reach filter): its six quotients, nothing to sort
+                        if (reach) {
+                            const uint32_t k = (uint32_t)__builtin_ctz(reach);                           // wave-uniform
+                            const bool ux = (0xCCu >> k) & 1u, uy = (0xF0u >> k) & 1u, uz = (0x66u >> k) & 1u;   // upper half per axis
+                            const double clx = ux ? N.mid[0] : N.lo[0], chx = ux ? N.hi[0] : N.mid[0];
+                            const double cly = uy ? N.mid[1] : N.lo[1], chy = uy ? N.hi[1] : N.mid[1];
+                            const double clz = uz ? N.mid[2] : N.lo[2], chz = uz ? N.hi[2] : N.mid[2];
                             double t = kInf;
                             PROF_ADD(8, 1); PROF_ADD(9, __popcll(__ballot(1)));
-                            if (((lane_reach >> k) & 1u) &&
-                                slab_from_quotients(hx[k] ? qmx : qlx, hx[k] ? qhx : qmx, hy[k] ? qmy : qly, hy[k] ? qhy : qmy, hz[k] ? qmz : qlz, hz[k] ? qhz : qmz, t)) {
-                                vk[k] = true; tk[k] = (t != t) ? kInf : t;                                              // NaN sorts last (reference panics, ray.rs:147)
+                            if (lane_reach &&
+                                slab_from_quotients((clx - o.x) / d.x, (chx - o.x) / d.x, (cly - o.y) / d.y, (chy - o.y) / d.y, (clz - o.z) / d.z, (chz - o.z) / d.z, t)) {
+                                order = k; nchild = 1u;
                             }
                         }
-                    }
-                    // stable ascending sort by t (ray.rs:146-147).  With a single candidate child (the usual case after the reach filter) there is
-                    // nothing to sort; otherwise a rank computation over the candidates only.
-                    if ((reach & (reach - 1u)) == 0u) {
-                        const bool any = vk[0] | vk[1] | vk[2] | vk[3] | vk[4] | vk[5] | vk[6] | vk[7];   // only the candidate's flag can be set
-                        order = reach ? (uint32_t)__builtin_ctz(reach) : 0u;
-                        nchild = any ? 1u : 0u;
                     } else {
+                    double qlx = 0, qmx = 0, qhx = 0, qly = 0, qmy = 0, qhy = 0, qlz = 0, qmz = 0, qhz = 0;
+                        if (reach & 0xFFu) { qmx = (N.mid[0] - o.x) / d.x; qmy = (N.mid[1] - o.y) / d.y; qmz = (N.mid[2] - o.z) / d.z; }
+                        if (reach & 0x33u) qlx = (N.lo[0] - o.x) / d.x;
+                        if (reach & 0xCCu) qhx = (N.hi[0] - o.x) / d.x;
+                        if (reach & 0x0Fu) qly = (N.lo[1] - o.y) / d.y;
+                        if (reach & 0xF0u) qhy = (N.hi[1] - o.y) / d.y;
+                        if (reach & 0x99u) qlz = (N.lo[2] - o.z) / d.z;
+                        if (reach & 0x66u) qhz = (N.hi[2] - o.z) / d.z;
+                        double tk[8]; bool vk[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            vk[k] = false; tk[k] = kInf;
+                            if (reach & (1u << k)) {
+                                constexpr int hx[8] = {0, 0, 1, 1, 0, 0, 1, 1}, hy[8] = {0, 0, 0, 0, 1, 1, 1, 1}, hz[8] = {0, 1, 1, 0, 0, 1, 1, 0};
+                                double t = kInf;
+                                PROF_ADD(8, 1); PROF_ADD(9, __popcll(__ballot(1)));
+                                if (((lane_reach >> k) & 1u) &&
+                                    slab_from_quotients(hx[k] ? qmx : qlx, hx[k] ? qhx : qmx, hy[k] ? qmy : qly, hy[k] ? qhy : qmy, hz[k] ? qmz : qlz, hz[k] ? qhz : qmz, t)) {
+                                    vk[k] = true; tk[k] = (t != t) ? kInf : t;                                              // NaN sorts last (reference panics, ray.rs:147)
+                                }
+                            }
+                        }
+                        // stable ascending sort by t (ray.rs:146-147) as a rank computation over the candidates only
 #pragma unroll
                         for (int k = 0; k < 8; ++k) {
                             if (!(reach & (1u << k))) continue;
@@ -454,6 +464,7 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                             if (vk[k]) { order |= (uint32_t)k << (3u * rank); nchild++; }
                         }
                     }
+
                 }
             }
         }
