@@ -624,7 +624,8 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
             }
             // A shadow query at the root that already holds an own hit (t < max_t) returns Some whatever the children do
             // (ray.rs:163-167 picks child or own, both Some), and only Some/None is used (raytracer.rs:183-187): stop here.
-            else if (fc == 0 || (any_ok && sp == 0 && own_slot != kNone)) {   // leaf: no children -> returns its own result (ray.rs:163-167 with child_dist = inf)
+            // A node none of whose children is entered (leaf, or no child box hit) returns its own result: ray.rs:163-167 with child_dist = inf.
+            else if (nchild == 0 || (any_ok && sp == 0 && own_slot != kNone)) {
                 returning = true; ret_slot = own_slot; ret_t = own_t;
             } else {
                 stk.own_slot(sp) = own_slot; stk.meta(sp) = order | (nchild << 24); stk.fc(sp) = fc;
