@@ -793,6 +793,9 @@ __device__ __forceinline__ uint32_t trace_colour(PROF_DECL const DevScene& S, co
 #ifdef RRT_ABL_NOLIGHTS
                     I = mk(1.0, 1.0, 1.0); n_eval = 0;
 #endif
+#ifdef RRT_ABL_NOLIGHTMATH   /* ablation build only: shadow rays traced, light arithmetic skipped */
+                    I = mk(0.5, 0.5, 0.5); n_eval = 0;
+#endif
                     for (uint32_t k = 0; k < n_eval; ++k) {
                         const DevLight& L = S.lights[k];
                         if (L.kind == 0u) {                                              // Ambient, raytracer.rs:207-209
