@@ -70,6 +70,14 @@ def main() -> None:
 
     rrt = importlib.import_module("rust-ray-tracer_amd")
     W, H = args.width, args.height
+    if args.scene.startswith("soup"):   # soup100000 / soup1000000: the synthetic configs of BASELINE.json, generated on the spot (rank 0 writes the .obj)
+        syn = importlib.import_module("rust-ray-tracer_amd.synthetic")
+        n = int(args.scene[4:])
+        if rank == 0:
+            syn.ensure_soup(os.path.join(ROOT, "assets"), n, syn.SEED_100K if n == 100000 else syn.SEED_1M if n == 1000000 else 0x5EED0003)
+        if world > 1:
+            dist.barrier()
+        args.scene = syn.ensure_soup(os.path.join(ROOT, "assets"), n, syn.SEED_100K if n == 100000 else syn.SEED_1M if n == 1000000 else 0x5EED0003)
     sd = rrt.parse_obj_file(args.scene)
     lights = rrt.default_lights()
     rt = rrt.RayTracer(sd, lights, rrt.DEFAULT_ORIGIN, device=local_rank)

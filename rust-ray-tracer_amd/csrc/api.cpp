@@ -318,9 +318,13 @@ int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n
                 d.mid[k] = T.first_child[i] ? T.box[T.first_child[i] + 6].lo[k] : d.lo[k] + (d.hi[k] - d.lo[k]) / 2.0;
             }
             d.first_child = T.first_child[i]; d.sup_begin = CS.node_sup_begin[i]; d.sup_count = CS.node_sup_count[i];
-            d.s0_begin = d.sup_count ? CS.supers[d.sup_begin].tri_begin : 0; d.s0_count = d.sup_count ? CS.supers[d.sup_begin].tri_count : 0;
-            d.flags = T.tri_count[i] ? 0x100u : 0u;
-            if (d.first_child) for (uint32_t k = 0; k < 8; k++) if (T.tri_count[d.first_child + k]) d.flags |= 1u << k;
+            d.s0_begin = d.sup_count ? CS.supers[d.sup_begin].tri_begin : 0;
+            d.flags = (T.tri_count[i] ? 0x100u : 0u) | ((d.sup_count ? CS.supers[d.sup_begin].tri_count : 0u) << 24);
+            d.leaf_base = CS.node_leaf_slot[i] != kPadSlot ? CS.node_leaf_slot[i] : 0;   // a leaf has no children: the field holds its own dense slot instead
+            if (d.first_child) for (uint32_t k = 8; k-- > 0;) {
+                if (T.tri_count[d.first_child + k]) d.flags |= 1u << k;
+                if (CS.node_leaf_slot[d.first_child + k] != kPadSlot) { d.flags |= 1u << (9 + k); d.leaf_base = CS.node_leaf_slot[d.first_child + k]; }   // ends at the first one
+            }
         }
         std::vector<DevTriGeom> geom(n_slots_c); std::vector<DevTriAttr> attr(n_slots_c);
         for (size_t s = 0; s < n_slots_c; s++) {
@@ -361,7 +365,7 @@ int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n
         S.mats = upload(rt.get(), mats.data(), mats.size());
         S.tex = upload(rt.get(), texs.data(), texs.size());
         S.n_nodes = (uint32_t)n_nodes; S.n_slots = (uint32_t)n_slots; S.n_mats = (uint32_t)mats.size(); S.n_tex = (uint32_t)texs.size();
-        S.n_lights = n_lights; S.max_reflection_depth = o.max_reflection_depth; S.stack_levels = T.max_depth > 1 ? T.max_depth - 1 : 1;   // only internal nodes push a frame; the deepest level holds leaves S._pad = 0;
+        S.n_lights = n_lights; S.max_reflection_depth = o.max_reflection_depth; S.stack_levels = T.max_depth > 1 ? T.max_depth - 1 : 1; S.fc_mask = CS.inline_leaves ? 0x00FFFFFFu : 0xFFFFFFFFu;   // only internal nodes push a frame; the deepest level holds leaves S._pad = 0;
         S.origin[0] = origin.x; S.origin[1] = origin.y; S.origin[2] = origin.z;
         S.surface_offset = o.surface_offset;
         for (uint32_t i = 0; i < n_lights; i++) {

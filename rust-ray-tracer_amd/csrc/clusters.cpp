@@ -63,6 +63,15 @@ void build_clusters(const Model& m, bool enable_cull, ClusterSet& out) {
     const size_t n_nodes = T.box.size();
     out = ClusterSet{};
     out.node_sup_begin.assign(n_nodes, 0); out.node_sup_count.assign(n_nodes, 0);
+    // Single-triangle leaves below the root (a non-empty leaf never holds more than one triangle, octree.rs:77-92): the lane-filter kernel
+    // tests such a child's triangle while it is at the PARENT (render.hip, "leaf children") and never enters the leaf.  For that the triangle
+    // gets a SECOND slot in a dense run after all list slots, in node-id order (siblings' triangles are adjacent in memory); the leaf keeps its
+    // ordinary own list as well, which the bundle-filter kernel (that enters leaves like any node) uses.  Both slots carry the same geometry and
+    // attributes.  The frame word that carries the leaf-hit mask keeps 24 bits for first_child, hence the node-count bound.
+    out.node_leaf_slot.assign(n_nodes, kPadSlot);
+    const bool inline_leaves = n_nodes < (1u << 24);
+    out.inline_leaves = inline_leaves;
+    auto is_inline_leaf = [&](size_t node) { return inline_leaves && node >= 1 && T.first_child[node] == 0 && T.own_off[node + 1] - T.own_off[node] == 1; };
     out.slot_tri.reserve(T.own_idx.size()); out.slot_pos.reserve(T.own_idx.size());
 
     double mag = 0;
@@ -129,6 +138,12 @@ void build_clusters(const Model& m, bool enable_cull, ClusterSet& out) {
         out.node_sup_count[node] = (uint32_t)out.supers.size() - out.node_sup_begin[node];
     }
     for (int i = 0; i < 8; i++) { out.cboxes.push_back(DevClusterBox{}); out.tboxes.push_back(DevClusterBox{}); }   // spare records: box bursts never leave the buffers
+    out.n_list_slots = (uint32_t)out.slot_tri.size();
+    for (size_t node = 1; node < n_nodes; node++) {
+        if (!is_inline_leaf(node)) continue;
+        out.node_leaf_slot[node] = (uint32_t)out.slot_tri.size();
+        out.slot_tri.push_back(T.own_idx[T.own_off[node]]); out.slot_pos.push_back(0);
+    }
 
     // ---- tight bounds of every subtree (all triangles counted by triangle_count, octree.rs:75), as padded f32 boxes grouped by sibling set.
     // A child whose subtree the ray cannot reach returns None (ray.rs:112-167 finds no triangle), exactly like an empty child, so the walk may

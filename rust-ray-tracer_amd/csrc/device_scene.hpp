@@ -19,8 +19,12 @@ struct DevNode {                 // 96 B
     uint32_t first_child;        // 0 = leaf; children are first_child..first_child+7 (octree.rs:226-238)
     uint32_t sup_begin;          // first super-cluster of this node's own triangle list (clusters.cpp)
     uint32_t sup_count;
-    uint32_t flags;              // bit k (0..7): child k has triangle_count > 0; bit 8: this node has triangle_count > 0 (ray.rs:112)
-    uint32_t s0_begin, s0_count; // slot range of the first super-cluster (the only one when sup_count == 1)
+    uint32_t flags;              // bit k (0..7): child k has triangle_count > 0; bit 8: this node has triangle_count > 0 (ray.rs:112);
+                                 // bit 9+k: child k is a single-triangle leaf whose triangle is tested here, at its parent (clusters.cpp);
+                                 // bits 24..30: number of slots of the first super-cluster (<= 64; the only one when sup_count == 1)
+    uint32_t s0_begin;           // first slot of the first super-cluster
+    uint32_t leaf_base;          // dense slot of the triangle of the first such leaf child; the j-th such child (in child order) has slot leaf_base + j.
+                                 // In the record of such a leaf itself: its own dense slot.
 };
 static_assert(sizeof(DevNode) == 96, "DevNode must be 96 bytes");
 
@@ -60,7 +64,8 @@ struct DevScene {                // passed to kernels by value (kernarg segment 
     const DevMaterial* mats;
     const DevTexture* tex;
     uint32_t n_nodes, n_slots, n_mats, n_tex;
-    uint32_t n_lights, max_reflection_depth, stack_levels, _pad;
+    uint32_t n_lights, max_reflection_depth, stack_levels;
+    uint32_t fc_mask;            // 0x00FFFFFF when stack frames carry a leaf-hit mask above first_child (scenes below 2^24 nodes), else 0xFFFFFFFF
     double origin[3];
     double surface_offset;
     float cull_limit;            // rays with |origin| or |direction| components beyond this (or non-finite) skip the box culling
@@ -99,6 +104,9 @@ struct ClusterSet {
     std::vector<DevClusterBox> cboxes;                 // one per 8 slots, + 8 spare records so a 4x64-byte burst never leaves the buffer
     std::vector<uint32_t> slot_tri, slot_pos;          // per device slot: triangle index in push order (kPadSlot for padding), position in its node's own list
     std::vector<uint32_t> node_sup_begin, node_sup_count;
+    std::vector<uint32_t> node_leaf_slot;              // slot of the triangle of a single-triangle leaf that is tested at its parent (kPadSlot otherwise)
+    bool inline_leaves = false;                        // single-triangle leaves are tested at their parents (node_leaf_slot, DevNode::leaf_base)
+    uint32_t n_list_slots = 0;                         // slots [0, n_list_slots) belong to own lists (cboxes/tboxes cover these); leaf slots follow
     double scene_magnitude = 0;
 };
 constexpr uint32_t kPadSlot = 0xFFFFFFFFu;

@@ -90,7 +90,7 @@ typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ double mkd(uint32_t lo, uint32_t hi) { return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo); }
 __device__ __forceinline__ float mkf(uint32_t x) { return __builtin_bit_cast(float, x); }
 
-struct UNode { double lo[3], hi[3], mid[3]; uint32_t first_child, sup_begin, sup_count, flags, s0_begin, s0_count; };
+struct UNode { double lo[3], hi[3], mid[3]; uint32_t first_child, sup_begin, sup_count, flags, s0_begin, s0_count, leaf_base; };
 __device__ __forceinline__ UNode load_unode(const RRT_CONSTANT DevNode* p) {
     const u32x16 a = *(const RRT_CONSTANT u32x16*)p;
     const u32x8 b = *(const RRT_CONSTANT u32x8*)((const RRT_CONSTANT char*)p + 64);
@@ -98,7 +98,7 @@ __device__ __forceinline__ UNode load_unode(const RRT_CONSTANT DevNode* p) {
     n.lo[0] = mkd(a[0], a[1]); n.lo[1] = mkd(a[2], a[3]); n.lo[2] = mkd(a[4], a[5]);
     n.hi[0] = mkd(a[6], a[7]); n.hi[1] = mkd(a[8], a[9]); n.hi[2] = mkd(a[10], a[11]);
     n.mid[0] = mkd(a[12], a[13]); n.mid[1] = mkd(a[14], a[15]); n.mid[2] = mkd(b[0], b[1]);
-    n.first_child = b[2]; n.sup_begin = b[3]; n.sup_count = b[4]; n.flags = b[5]; n.s0_begin = b[6]; n.s0_count = b[7];
+    n.first_child = b[2]; n.sup_begin = b[3]; n.sup_count = b[4]; n.flags = b[5]; n.s0_begin = b[6]; n.s0_count = b[5] >> 24; n.leaf_base = b[7];
     return n;
 }
 
@@ -352,6 +352,7 @@ __device__ __forceinline__ uint32_t lane_read(uint32_t v, uint32_t src_lane) { r
 template <bool kBundle>
 __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stack& stk, bool active, bool any_ok, V3 o, V3 d, double max_t,
                                          double& out_t, uint32_t& out_slot) {
+    constexpr bool kLeaf = !kBundle;   // leaf children are tested at their parent by the lane-filter kernel only (measured: the extra code costs the bundle kernel 12 % on the teapot)
     bool done = !active;
     uint32_t cur = 0;        // node this lane has to enter next
     uint32_t sp = 0;         // number of frames on this lane's stack == depth of `cur`
@@ -383,6 +384,7 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
         PROF_T(0);                                                       // [0] pick node + node record load
         const bool mine = !done && cur == unode;
         uint32_t order = 0, nchild = 0;
+        uint32_t leaf_hit = 0;                                           // bit k: child k is a leaf whose triangle this lane's ray hits
         if (mine && (fl & 0x100u)) {
             {
                 // ---- children first (their boxes are this node's lo/mid/hi, which can then leave the SGPRs): slab test in child order
@@ -426,6 +428,13 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                                 slab_from_quotients((clx - o.x) / d.x, (chx - o.x) / d.x, (cly - o.y) / d.y, (chy - o.y) / d.y, (clz - o.z) / d.z, (chz - o.z) / d.z, t)) {
                                 order = k; nchild = 1u;
                             }
+                            if (kLeaf && ((fl >> (9u + k)) & 1u)) {
+                                // leaf child (see below): its one triangle is tested here; a miss means the child returns None
+                                const UTri tri = load_utri(geom + N.leaf_base + (uint32_t)__builtin_popcount((fl >> 9) & ((1u << k) - 1u)));
+                                double tl;
+                                PROF_ADD(2, 1); PROF_ADD(3, __popcll(__ballot(nchild != 0u)));
+                                if (nchild) { if (mt_uniform(tri, o, d, tl)) leaf_hit = 1u << k; else nchild = 0u; }
+                            }
                         }
                     } else {
                     double qlx = 0, qmx = 0, qhx = 0, qly = 0, qmy = 0, qhy = 0, qlz = 0, qmz = 0, qhz = 0;
@@ -449,6 +458,34 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                                     vk[k] = true; tk[k] = (t != t) ? kInf : t;                                              // NaN sorts last (reference panics, ray.rs:147)
                                 }
                             }
+                        }
+                        // LEAF CHILDREN.  A non-empty leaf holds exactly one triangle (octree.rs:77-92), so entering it (ray.rs:112-129 with
+                        // max_t = +inf, no children) returns Some(that triangle) iff the ray hits it.  Such children are not visited as nodes: their
+                        // triangle (slot leaf_base + rank among the leaf children, geometry adjacent in memory) is tested here by the lanes whose exact
+                        // box test entered the child; a miss drops the child from the sorted list (it would have returned None), a hit keeps it and
+                        // marks it in the frame, and the unwind takes (t, slot) from there when the walk reaches it in sorted order.
+                        uint32_t lm = kLeaf ? ((fl >> 9) & reach) : 0u;                                     // wave-uniform
+                        if (lm) {
+                            uint32_t vmask = 0;
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) vmask |= vk[k] ? (1u << k) : 0u;
+                            uint32_t k = (uint32_t)__builtin_ctz(lm);
+                            lm &= lm - 1u;
+                            UTri tri = load_utri(geom + N.leaf_base + (uint32_t)__builtin_popcount((fl >> 9) & ((1u << k) - 1u)));
+                            for (;;) {
+                                const uint32_t k_next = lm ? (uint32_t)__builtin_ctz(lm) : k;
+                                UTri nxt = tri;
+                                if (lm) nxt = load_utri(geom + N.leaf_base + (uint32_t)__builtin_popcount((fl >> 9) & ((1u << k_next) - 1u)));   // scalar prefetch
+                                double tl;
+                                const bool cand = (vmask >> k) & 1u;
+                                PROF_ADD(2, 1); PROF_ADD(3, __popcll(__ballot(cand)));
+                                if (cand) { if (mt_uniform(tri, o, d, tl)) leaf_hit |= 1u << k; else vmask &= ~(1u << k); }
+                                if (!lm) break;
+                                lm &= lm - 1u;
+                                tri = nxt; k = k_next;
+                            }
+#pragma unroll
+                            for (int k2 = 0; k2 < 8; ++k2) vk[k2] = (vmask >> k2) & 1u;
                         }
                         // stable ascending sort by t (ray.rs:146-147) as a rank computation over the candidates only
 #pragma unroll
@@ -628,7 +665,7 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
             else if (nchild == 0 || (any_ok && sp == 0 && own_slot != kNone)) {
                 returning = true; ret_slot = own_slot; ret_t = own_t;
             } else {
-                stk.own_slot(sp) = own_slot; stk.meta(sp) = order | (nchild << 24); stk.fc(sp) = fc;
+                stk.own_slot(sp) = own_slot; stk.meta(sp) = order | (nchild << 24); stk.fc(sp) = fc | (leaf_hit << 24);   // first_child < 2^24 whenever leaf bits exist (clusters.cpp)
                 sp++;
                 returning = false;
             }
@@ -639,12 +676,18 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                     const uint32_t cursor = m >> 28, n = (m >> 24) & 15u;
                     if (cursor < n) {                                    // next sorted child, entered with max_t = +inf (ray.rs:153)
                         stk.meta(sp - 1) = m + (1u << 28);
-                        cur = stk.fc(sp - 1) + ((m >> (3u * cursor)) & 7u);
-                        break;
+                        const uint32_t fcw = stk.fc(sp - 1), k = (m >> (3u * cursor)) & 7u;
+                        const uint32_t fcm = kLeaf ? S.fc_mask : 0xFFFFFFFFu;
+                        if (!(((fcw & ~fcm) >> (24u + k)) & 1u)) { cur = (fcw & fcm) + k; break; }
+                        // a leaf child whose triangle this ray hits (tested at the parent, above): it returns Some(t, triangle) without a visit;
+                        // a leaf's own record holds its dense slot in leaf_base (it has no children to describe)
+                        ret_slot = S.nodes[(fcw & fcm) + k].leaf_base;
+                        ret_t = t_of_slot(S.geom + ret_slot, o, d);
+                    } else {
+                        ret_slot = stk.own_slot(sp - 1);                     // no child hit: child_dist = inf -> own (ray.rs:163-167)
+                        ret_t = (ret_slot != kNone) ? t_of_slot(S.geom + ret_slot, o, d) : kInf;
+                        sp--;
                     }
-                    ret_slot = stk.own_slot(sp - 1);                         // no child hit: child_dist = inf -> own (ray.rs:163-167)
-                    ret_t = (ret_slot != kNone) ? t_of_slot(S.geom + ret_slot, o, d) : kInf;
-                    sp--;
                     returning = true;
                 }
                 if (sp == 0) { done = true; break; }

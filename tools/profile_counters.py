@@ -8,6 +8,9 @@ os.environ.setdefault("RRT_LIB", os.path.join(ROOT, "rust-ray-tracer_amd", "libr
 rrt = importlib.import_module("rust-ray-tracer_amd")
 W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1920, 1080)
 scene = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "assets/model2.obj")
+if scene.startswith("soup"):   # soup100000 / soup1000000: generated on the spot (the .obj files are not shipped)
+    syn = importlib.import_module("rust-ray-tracer_amd.synthetic"); n = int(scene[4:])
+    scene = syn.ensure_soup(os.path.join(ROOT, "assets"), n, syn.SEED_100K if n == 100000 else syn.SEED_1M if n == 1000000 else 0x5EED0003)
 sd = rrt.parse_obj_file(scene)
 rt = rrt.RayTracer(sd, rrt.default_lights(), box_filter=os.environ.get("RRT_FILTER") or None)
 L = rrt.lib()
