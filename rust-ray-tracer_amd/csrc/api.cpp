@@ -360,6 +360,11 @@ int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n
         S.child_boxes = upload(rt.get(), CS.child_boxes.data(), CS.child_boxes.size());
         S.tboxes = upload(rt.get(), CS.tboxes.data(), CS.tboxes.size());
         S.cull_enabled = (o.flags & RRT_FLAG_NO_CULL) ? 0u : 1u;
+        S.bounds_plain = 1u;
+        for (const DevNode& d : nodes)
+            for (int k = 0; k < 3; k++)
+                for (double v : {d.lo[k], d.mid[k], d.hi[k]})
+                    if (!(v == 0.0 || (std::fabs(v) > 0x1p-200 && std::fabs(v) < 0x1p200))) S.bounds_plain = 0u;
         S.cull_limit = (float)(CS.scene_magnitude * 4.0);
         S.attr = upload(rt.get(), attr.data(), attr.size());
         S.mats = upload(rt.get(), mats.data(), mats.size());

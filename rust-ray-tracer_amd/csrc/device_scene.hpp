@@ -70,6 +70,7 @@ struct DevScene {                // passed to kernels by value (kernarg segment 
     double surface_offset;
     float cull_limit;            // rays with |origin| or |direction| components beyond this (or non-finite) skip the box culling
     uint32_t cull_enabled;
+    uint32_t bounds_plain;       // every node plane (lo, mid, hi) is 0 or has magnitude in [2^-200, 2^200]: the walk may share the reciprocal of a ray's direction across its slab quotients (render.hip, RayRcp)
     DevLight lights[RRT_MAX_LIGHTS];
 #ifdef RRT_PROFILE
     unsigned long long* prof;    // developer build only (make prof): 16 wave-level work counters + 8 s_memtime region timers, see tools/profile_counters.py

@@ -54,10 +54,13 @@ __device__ __forceinline__ V3 cross(V3 a, V3 b) {                               
 //   s0 = div_scale(b,b,a); r = rcp(s0); two Newton steps on r; s1 = div_scale(a,b,a); q = s1*r; q = div_fmas(fma(-s0,q,s1), r, q); div_fixup(q,b,a)
 // and the first half depends on the denominator only whenever v_div_scale leaves its operands alone (every exponent within +-500 here).
 // Sharing it between the three numerators is therefore the SAME instruction sequence per quotient, 18 instructions instead of 39.
-__device__ __forceinline__ bool div_plain(double x) { const double a = fabs(x); return x == 0.0 || (a > 0x1p-500 && a < 0x1p500); }
+// (v_div_scale_f64 leaves both operands alone and clears VCC when the denominator is normal with 1/den normal, the numerator is not tiny
+// (exponent > -970), num/den is normal and exponent(num) - exponent(den) < 768; a zero numerator makes it return NaN, but v_div_fixup_f64 then
+// returns the signed zero whatever the quotient register holds.  |den| in [2^-500, 2^500] and |num| in [2^-252, 2^250] or 0 satisfy all of it.)
+__device__ __forceinline__ bool div_plain(double x) { const double a = fabs(x); return x == 0.0 || (a > 0x1p-250 && a < 0x1p250); }
+__device__ __forceinline__ bool den_plain(double x) { const double a = fabs(x); return a > 0x1p-500 && a < 0x1p500; }
 __device__ __forceinline__ V3 div3(V3 a, double b) {
-    const double ab = fabs(b);
-    if (!(ab > 0x1p-500 && ab < 0x1p500 && div_plain(a.x) && div_plain(a.y) && div_plain(a.z))) return mk(a.x / b, a.y / b, a.z / b);
+    if (!(den_plain(b) && div_plain(a.x) && div_plain(a.y) && div_plain(a.z))) return mk(a.x / b, a.y / b, a.z / b);
     double r = __builtin_amdgcn_rcp(b);
     double e = __builtin_fma(-b, r, 1.0); r = __builtin_fma(r, e, r);
     e = __builtin_fma(-b, r, 1.0); r = __builtin_fma(r, e, r);
@@ -68,6 +71,33 @@ __device__ __forceinline__ V3 div3(V3 a, double b) {
     return mk(__builtin_amdgcn_div_fixup(qx, b, a.x), __builtin_amdgcn_div_fixup(qy, b, a.y), __builtin_amdgcn_div_fixup(qz, b, a.z));
 }
 __device__ __forceinline__ V3 normalised(V3 a) { return div3(a, length(a)); }                          // engine.rs:101-103
+
+// The same sharing across a whole walk: every slab quotient (bound - o)/d of ray.rs:22-27 divides by one of the ray's three direction
+// components, so the denominator half of the divide (rcp + two Newton steps) is done once per ray and axis, and each quotient is the
+// numerator half only -- mul, fma, fma, div_fixup: the instructions hipcc emits for `/`, hence the same bits.  `plain` says that no
+// v_div_scale in those divides would rescale: d plain as a denominator, every origin component 0 or in [2^-200, 2^200], and (host-checked,
+// DevScene::bounds_plain) every node plane 0 or in [2^-200, 2^200] -- a non-zero difference of two such numbers is at least 2^-252 in
+// magnitude.  Lanes that are not plain use the ordinary divide.
+struct RayRcp { double rx, ry, rz; bool plain; };
+__device__ __forceinline__ double rcp_refined(double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, r, 1.0); r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-b, r, 1.0); r = __builtin_fma(r, e, r);
+    return r;
+}
+__device__ __forceinline__ bool org_plain(double x) { const double a = fabs(x); return x == 0.0 || (a > 0x1p-200 && a < 0x1p200); }
+__device__ __forceinline__ RayRcp make_ray_rcp(V3 o, V3 d, bool bounds_plain) {
+    RayRcp R;
+    R.plain = bounds_plain && den_plain(d.x) && den_plain(d.y) && den_plain(d.z) && org_plain(o.x) && org_plain(o.y) && org_plain(o.z);
+    R.rx = rcp_refined(d.x); R.ry = rcp_refined(d.y); R.rz = rcp_refined(d.z);
+    return R;
+}
+// num / den for a plain pair, given r = rcp_refined(den)
+__device__ __forceinline__ double quot(double num, double den, double r) {
+    double q = num * r;
+    q = __builtin_fma(__builtin_fma(-den, q, num), r, q);
+    return __builtin_amdgcn_div_fixup(q, den, num);
+}
 
 // ------------------------------------------------------------------------------------------------ LDS stack
 // per wave: levels x 768 B, level record = own_slot[64] u32 | meta[64] u32 | fc[64] u32.  A frame does not keep the t of its own hit: the few
@@ -364,6 +394,10 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
     const RRT_CONSTANT DevClusterBox* child_boxes = (const RRT_CONSTANT DevClusterBox*)S.child_boxes;
     const RRT_CONSTANT DevClusterBox* tboxes = (const RRT_CONSTANT DevClusterBox*)S.tboxes;
     const Ray32 r32 = make_ray32(o, d, S.cull_limit, S.cull_enabled != 0);
+    // (lane-filter kernel only: with ~2 slab tests per walk on coherent frames the per-walk set-up costs the bundle-filter kernel what the
+    // cheaper quotients save -- measured, rocprofv3 SQ_INSTS_VALU 502.8 M -> 495.6 M per teapot frame but 2 % slower; the soups gain 2 %)
+    RayRcp RR; RR.rx = RR.ry = RR.rz = 0.0; RR.plain = false;
+    if constexpr (!kBundle) RR = make_ray_rcp(o, d, S.bounds_plain != 0);
     Bundle BU{};
     if constexpr (kBundle) BU = make_bundle(active, o, r32);
 
@@ -424,9 +458,15 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                             const double clz = uz ? N.mid[2] : N.lo[2], chz = uz ? N.hi[2] : N.mid[2];
                             double t = kInf;
                             PROF_ADD(8, 1); PROF_ADD(9, __popcll(__ballot(1)));
-                            if (lane_reach &&
-                                slab_from_quotients((clx - o.x) / d.x, (chx - o.x) / d.x, (cly - o.y) / d.y, (chy - o.y) / d.y, (clz - o.z) / d.z, (chz - o.z) / d.z, t)) {
-                                order = k; nchild = 1u;
+                            if (lane_reach) {
+                                double t1, t2, t3, t4, t5, t6;
+                                if (RR.plain) {
+                                    t1 = quot(clx - o.x, d.x, RR.rx); t2 = quot(chx - o.x, d.x, RR.rx); t3 = quot(cly - o.y, d.y, RR.ry);
+                                    t4 = quot(chy - o.y, d.y, RR.ry); t5 = quot(clz - o.z, d.z, RR.rz); t6 = quot(chz - o.z, d.z, RR.rz);
+                                } else {
+                                    t1 = (clx - o.x) / d.x; t2 = (chx - o.x) / d.x; t3 = (cly - o.y) / d.y; t4 = (chy - o.y) / d.y; t5 = (clz - o.z) / d.z; t6 = (chz - o.z) / d.z;
+                                }
+                                if (slab_from_quotients(t1, t2, t3, t4, t5, t6, t)) { order = k; nchild = 1u; }
                             }
                             if (kLeaf && ((fl >> (9u + k)) & 1u)) {
                                 // leaf child (see below): its one triangle is tested here; a miss means the child returns None
@@ -438,13 +478,23 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                         }
                     } else {
                     double qlx = 0, qmx = 0, qhx = 0, qly = 0, qmy = 0, qhy = 0, qlz = 0, qmz = 0, qhz = 0;
-                        if (reach & 0xFFu) { qmx = (N.mid[0] - o.x) / d.x; qmy = (N.mid[1] - o.y) / d.y; qmz = (N.mid[2] - o.z) / d.z; }
-                        if (reach & 0x33u) qlx = (N.lo[0] - o.x) / d.x;
-                        if (reach & 0xCCu) qhx = (N.hi[0] - o.x) / d.x;
-                        if (reach & 0x0Fu) qly = (N.lo[1] - o.y) / d.y;
-                        if (reach & 0xF0u) qhy = (N.hi[1] - o.y) / d.y;
-                        if (reach & 0x99u) qlz = (N.lo[2] - o.z) / d.z;
-                        if (reach & 0x66u) qhz = (N.hi[2] - o.z) / d.z;
+                        if (RR.plain) {
+                            qmx = quot(N.mid[0] - o.x, d.x, RR.rx); qmy = quot(N.mid[1] - o.y, d.y, RR.ry); qmz = quot(N.mid[2] - o.z, d.z, RR.rz);
+                            if (reach & 0x33u) qlx = quot(N.lo[0] - o.x, d.x, RR.rx);
+                            if (reach & 0xCCu) qhx = quot(N.hi[0] - o.x, d.x, RR.rx);
+                            if (reach & 0x0Fu) qly = quot(N.lo[1] - o.y, d.y, RR.ry);
+                            if (reach & 0xF0u) qhy = quot(N.hi[1] - o.y, d.y, RR.ry);
+                            if (reach & 0x99u) qlz = quot(N.lo[2] - o.z, d.z, RR.rz);
+                            if (reach & 0x66u) qhz = quot(N.hi[2] - o.z, d.z, RR.rz);
+                        } else {
+                            qmx = (N.mid[0] - o.x) / d.x; qmy = (N.mid[1] - o.y) / d.y; qmz = (N.mid[2] - o.z) / d.z;
+                            if (reach & 0x33u) qlx = (N.lo[0] - o.x) / d.x;
+                            if (reach & 0xCCu) qhx = (N.hi[0] - o.x) / d.x;
+                            if (reach & 0x0Fu) qly = (N.lo[1] - o.y) / d.y;
+                            if (reach & 0xF0u) qhy = (N.hi[1] - o.y) / d.y;
+                            if (reach & 0x99u) qlz = (N.lo[2] - o.z) / d.z;
+                            if (reach & 0x66u) qhz = (N.hi[2] - o.z) / d.z;
+                        }
                         double tk[8]; bool vk[8];
 #pragma unroll
                         for (int k = 0; k < 8; ++k) {
