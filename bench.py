@@ -42,9 +42,16 @@ def main() -> None:
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scene", default=os.path.join(ROOT, "assets", "model2.obj"))
+    ap.add_argument("--pipeline-depth", type=int, default=2, help="N > 1: frames in flight (gather + de-tiling of a frame overlap the tracing of the next); 1 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the bounded cpu_baseline sample")
     args = ap.parse_args()
+
+    # stdout carries exactly ONE line, the JSON: RCCL prints a version banner and gloo its connection notes to fd 1 while the process group
+    # comes up, so fd 1 points at stderr until the result is printed.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -61,8 +68,11 @@ def main() -> None:
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # RRT_BENCH_FORCE_DIST=1: developer check of the N > 1 choreography (RCCL gather, side stream, frames in flight) with ONE rank on one GPU
+    multi = world > 1 or os.environ.get("RRT_BENCH_FORCE_DIST") == "1"
+    if multi:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if rehearsal:
             dist.init_process_group("gloo")
         else:
@@ -83,36 +93,59 @@ def main() -> None:
     rt = rrt.RayTracer(sd, lights, rrt.DEFAULT_ORIGIN, device=local_rank)
 
     fb = torch.zeros((H, W), dtype=torch.int32, device="cuda")
-    if world > 1:
+    DEPTH = max(1, args.pipeline_depth) if multi else 1
+    if multi:
+        # Frames in flight: frame i's gather (RCCL stream) and de-tiling (side stream on GPU 0) overlap the tracing of frame i+1, so each of the
+        # DEPTH slots has its own tile buffer, gather buffer and completion handles.  Every frame still goes trace -> gather -> de-tile in full.
         tpr = rrt.tiles_per_rank(W, H, world)
-        mine = torch.zeros(tpr * 64, dtype=torch.int32, device="cuda")
-        gathered = torch.zeros(world * tpr * 64, dtype=torch.int32, device="cuda")
+        mine = [torch.zeros(tpr * 64, dtype=torch.int32, device="cuda") for _ in range(DEPTH)]
+        gathered = [torch.zeros(world * tpr * 64, dtype=torch.int32, device="cuda") for _ in range(DEPTH)] if rank == 0 else [None] * DEPTH
         # final gather to GPU 0 (BASELINE.json north_star): grouped point-to-point sends, every peer on its own xGMI link -- not a ring
-        chunks = [gathered[i * tpr * 64:(i + 1) * tpr * 64] for i in range(world)] if rank == 0 else None
+        chunks = [[g[i * tpr * 64:(i + 1) * tpr * 64] for i in range(world)] if rank == 0 else None for g in gathered]
+        side = torch.cuda.Stream() if (rank == 0 and not rehearsal) else None       # de-tiling stream of GPU 0
+        gather_work = [None] * DEPTH                                                # outstanding gather of each slot
+        detile_done = [torch.cuda.Event() for _ in range(DEPTH)]                    # slot's gather buffer has been de-tiled (GPU 0)
+        detile_pending = [False] * DEPTH
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     # pre-bound launchers: one ctypes call per launch in the timed loop
-    if world == 1:
+    if not multi:
         launch_frame = rt.bind_render(fb, W, H)
     else:
-        launch_tiles = rt.bind_render_tiles(mine, W, H, rank, world)
-        launch_detile = rt.bind_detile(gathered, fb, W, H, world) if rank == 0 else None
+        launch_tiles = [rt.bind_render_tiles(m, W, H, rank, world) for m in mine]
+        launch_detile = [rt.bind_detile(g, fb, W, H, world, stream=(side.cuda_stream if side is not None else None)) for g in gathered] if rank == 0 else None
+    frame_no = [0]
 
     def step(i: int | None) -> None:
-        if world == 1:
+        if not multi:
             if i is not None: ev[i][0].record()
             launch_frame()
             if i is not None: ev[i][1].record()
-        else:
-            if i is not None: ev[i][0].record()
-            launch_tiles()
-            if i is not None: ev[i][1].record()
-            dist.gather(mine, chunks, dst=0)
-            if rank == 0:
-                launch_detile()
+            return
+        b = frame_no[0] % DEPTH; frame_no[0] += 1
+        if gather_work[b] is not None:
+            gather_work[b].wait()                            # the slot's previous gather has read mine[b] (orders the current stream after it; host does not block on RCCL)
+        if rank == 0 and detile_pending[b]:
+            torch.cuda.current_stream().wait_event(detile_done[b])   # ... and its gather buffer has been consumed before the next gather (issued after this point) overwrites it
+        if i is not None: ev[i][0].record()
+        launch_tiles[b]()
+        if i is not None: ev[i][1].record()
+        gather_work[b] = dist.gather(mine[b], chunks[b], dst=0, async_op=True)
+        if rank == 0:
+            if side is None:                                 # rehearsal (gloo): synchronous
+                gather_work[b].wait(); gather_work[b] = None
+                launch_detile[b]()
+            else:
+                with torch.cuda.stream(side):
+                    gather_work[b].wait()                    # side stream waits for the gather; the tracing stream goes on with the next frame
+                    launch_detile[b]()
+                    detile_done[b].record(side); detile_pending[b] = True
 
     def fence() -> None:
-        if world > 1:
+        if multi:
+            for w in gather_work:
+                if w is not None: w.wait()
+            torch.cuda.synchronize()
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -228,7 +261,7 @@ def main() -> None:
                "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "reference scene assets/model2.obj (teapot+table+mirror, 6334 triangles), camera/lights of main.rs"
                if os.path.basename(args.scene) == "model2.obj" else "synthetic",
                "config": {"workload": f"{os.path.basename(args.scene)} {W}x{H}, 4 sub-samples/pixel, shadow rays + depth-5 mirror reflection, f64",
-                          "rays_primary_per_frame": rays_primary, "partition": "single launch" if world == 1 else f"8x8-pixel tiles round-robin over {world} GPUs + RCCL gather to GPU 0",
+                          "rays_primary_per_frame": rays_primary, "partition": "single launch" if world == 1 else f"8x8-pixel tiles round-robin over {world} GPUs + RCCL gather to GPU 0, {DEPTH} frames in flight",
                           "octree_nodes": sd.info["n_nodes"], "triangles": sd.info["n_tris"]},
                "frame_ms": round(ms_per_step, 4), "kernel_ms": round(kernel_ms, 4), **({"rehearsal": "gloo on one GPU: NOT a benchmark result"} if rehearsal else {}),
                "frame_checksum": int(np.bitwise_xor.reduce(frame.ravel().astype(np.uint64) * np.arange(1, frame.size + 1, dtype=np.uint64)))}
@@ -236,9 +269,12 @@ def main() -> None:
             out["roofline"] = roofline
         if cpu is not None:
             out["cpu_baseline"] = cpu
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
 
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
