@@ -140,6 +140,15 @@ int rrt_render_tiles_device(rrt_raytracer *rt, uint32_t width, uint32_t height, 
 int rrt_detile_device(rrt_raytracer *rt, uint32_t width, uint32_t height, uint32_t world, const void *d_gathered,
                       void *d_fb, void *stream);
 
+/* Scene::draw_scene with the reference's progressive display (engine.rs:196-253): the scene rows are traced in chunks of chunk_rows (0 = the
+ * reference's 50) from y = -H/2 upward, i.e. from the BOTTOM of the canvas to the top (put_pixel, engine.rs:146-158); after each chunk its rows are
+ * in out_fb (zero-initialised like Canvas::new, engine.rs:135) and on_update -- the stand-in for canvas.update(), engine.rs:253 -- is called on the
+ * calling thread with the canvas rows [first_row, first_row + n_rows) that the chunk wrote (n_rows = 0 for a chunk that wrote none).  The finished
+ * frame equals rrt_render's.  on_update may be NULL. */
+typedef void (*rrt_update_fn)(void *user, const uint32_t *fb, uint32_t width, uint32_t height, uint32_t first_row, uint32_t n_rows);
+int rrt_render_progressive(rrt_raytracer *rt, uint32_t width, uint32_t height, uint32_t *out_fb, uint32_t chunk_rows,
+                           rrt_update_fn on_update, void *user);
+
 /* Batched RayTracer::get_ray_colour (raytracer.rs:29): n rays, origins/dirs [n][3] host doubles -> colours[n] 0x00RRGGBB. */
 int rrt_get_ray_colours(rrt_raytracer *rt, uint32_t n, const double *origins, const double *dirs, uint32_t *colours);
 

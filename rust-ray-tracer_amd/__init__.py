@@ -88,6 +88,7 @@ SYMBOLS = {
     "rrt_tiles_per_rank": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32]),
     "rrt_render_tiles_device": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P]),
     "rrt_detile_device": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P]),
+    "rrt_render_progressive": (C.c_int, [_P, C.c_uint32, C.c_uint32, _u32p, C.c_uint32, _P, _P]),
     "rrt_get_ray_colours": (C.c_int, [_P, C.c_uint32, _dp, _dp, _u32p]),
     "rrt_intersect_rays": (C.c_int, [_P, C.c_uint32, _dp, _dp, _dp, _u8p, _dp, _dp, _dp, _u32p]),
     "rrt_last_stats": (C.c_int, [_P, C.POINTER(CStats)]),
@@ -300,6 +301,15 @@ class RayTracer:
                                         tri.ctypes.data_as(_u32p)), "rrt_intersect_rays")
         return hit.astype(bool), t, u, v, tri
 
+    # engine.rs:196-253: chunked draw with an update after every chunk (on_update(fb, first_row, n_rows) stands in for canvas.update())
+    def render_progressive(self, width: int, height: int, on_update=None, chunk_rows: int = 50) -> np.ndarray:
+        fb = np.empty((height, width), np.uint32)
+        UPD = C.CFUNCTYPE(None, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32)
+        cb = UPD(lambda user, p, w, h, r0, n: on_update(fb, int(r0), int(n))) if on_update is not None else None
+        _check(lib().rrt_render_progressive(self._h, width, height, fb.ctypes.data_as(_u32p), chunk_rows, C.cast(cb, _P) if cb is not None else None, None),
+               "rrt_render_progressive")
+        return fb
+
     # engine.rs:186 via the C ABI, host framebuffer
     def render(self, width: int, height: int) -> np.ndarray:
         fb = np.empty((height, width), np.uint32)
@@ -388,15 +398,31 @@ def detile_host(gathered: np.ndarray, width: int, height: int, world: int) -> np
 
 
 class Canvas:                        # src/scene/engine.rs:123-167 minus the minifb window
-    def __init__(self, width: int, height: int):
+    def __init__(self, width: int, height: int, on_update=None):
         self.width, self.height = width, height
         self.buffer = np.zeros((height, width), np.uint32)   # engine.rs:135
+        self.on_update = on_update                           # stands in for window.update_with_buffer (engine.rs:162-166); None = no display
+        self.updates = 0
+
+    def update(self) -> None:                                # engine.rs:160-167
+        self.updates += 1
+        if self.on_update is not None:
+            self.on_update(self.buffer)
 
 
 class Scene:                         # src/scene/engine.rs:171-256
-    def __init__(self, width: int, height: int):
-        self.canvas = Canvas(width, height)
+    def __init__(self, width: int, height: int, on_update=None):
+        self.canvas = Canvas(width, height, on_update)
 
-    def draw_scene(self, rt: RayTracer) -> None:
-        """Scene::draw_scene (engine.rs:186): one HIP launch instead of the rayon row loop; fills canvas.buffer."""
-        self.canvas.buffer = rt.render(self.canvas.width, self.canvas.height)
+    def draw_scene(self, rt: RayTracer, progressive: bool = False) -> None:
+        """Scene::draw_scene (engine.rs:186).  Default: one HIP launch instead of the rayon row loop, one canvas.update() at the end.
+        progressive=True keeps the reference's pacing (engine.rs:196-253): 50 scene rows per chunk, canvas.update() after each."""
+        if not progressive:
+            self.canvas.buffer = rt.render(self.canvas.width, self.canvas.height)
+            self.canvas.update()
+            return
+
+        def on_chunk(fb, first_row, n_rows):
+            self.canvas.buffer = fb
+            self.canvas.update()
+        self.canvas.buffer = rt.render_progressive(self.canvas.width, self.canvas.height, on_chunk)

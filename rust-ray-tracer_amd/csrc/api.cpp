@@ -98,6 +98,7 @@ FrameParams frame_params(const rrt_raytracer* rt, uint32_t width, uint32_t heigh
     f.z_value = rt->opt.vp_d;                      // engine.rs:191
     f.tiles_x = (width + 7) / 8; f.tiles_y = (height + 7) / 8;
     f.rank = rank; f.world = world; f.tiled_output = tiled ? 1u : 0u;
+    f.tile_begin = 0; f.tile_end = f.tiles_x * f.tiles_y; f.row_begin = 0; f.row_end = height;
     return f;
 }
 
@@ -465,6 +466,46 @@ int rrt_render(rrt_raytracer* rt, uint32_t width, uint32_t height, uint32_t* out
         const int rc = rrt_render_device(rt, width, height, rt->host_fb, nullptr);
         if (rc != RRT_OK) return rc;
         HIP_TRY(hipMemcpy(out_fb, rt->host_fb, bytes, hipMemcpyDeviceToHost));   // blocking: the frame is in out_fb on return
+        return RRT_OK;
+    });
+}
+
+// Scene::draw_scene as the reference paces it (engine.rs:196-253): the scene rows y in [-H/2, H/2) in chunks of `chunk_rows` (50 there), each chunk
+// traced, put into the canvas (put_pixel, engine.rs:146-158: scene row y -> canvas row H - (y + H/2), i.e. bottom-up), then canvas.update().
+int rrt_render_progressive(rrt_raytracer* rt, uint32_t width, uint32_t height, uint32_t* out_fb, uint32_t chunk_rows, rrt_update_fn on_update, void* user) {
+    return guarded([&]() -> int {
+        check_frame(rt, width, height);
+        if (!out_fb) throw Error{RRT_ERR_INVALID_ARG, "null framebuffer"};
+        if (chunk_rows == 0) chunk_rows = 50;                              // engine.rs:195
+        DeviceGuard guard(rt->device);
+        const size_t bytes = sizeof(uint32_t) * (size_t)width * height;
+        if (rt->host_fb_bytes < bytes) {
+            if (rt->host_fb) { (void)hipFree(rt->host_fb); rt->host_fb = nullptr; rt->host_fb_bytes = 0; }
+            HIP_TRY(hipMalloc(&rt->host_fb, bytes));
+            rt->host_fb_bytes = bytes;
+        }
+        uint32_t* d_fb = static_cast<uint32_t*>(rt->host_fb);
+        FrameParams f = frame_params(rt, width, height, 0, 1, false);
+        tune_variant(rt, f, d_fb, nullptr);                               // (first frame of a new size: picks the filter variant on the full frame)
+        HIP_TRY(hipMemsetAsync(d_fb, 0, bytes, nullptr));                  // Canvas::new, engine.rs:135
+        std::memset(out_fb, 0, bytes);
+        const int64_t H = height, half = H / 2;
+        HIP_TRY(hipEventRecord(rt->ev0, nullptr));
+        for (int64_t cs = -half; cs < half; cs += chunk_rows) {            // engine.rs:198-199
+            const int64_t ce = std::min<int64_t>(cs + chunk_rows, half);
+            // canvas rows of the scene rows [cs, ce): H - (y + H/2); the row that lands on H (y = -H/2) is rejected by put_pixel (engine.rs:152-155)
+            const int64_t r_lo = H - (ce - 1 + half), r_hi = std::min<int64_t>(H - (cs + half), H - 1);   // inclusive
+            if (r_lo <= r_hi) {
+                f.row_begin = (uint32_t)r_lo; f.row_end = (uint32_t)r_hi + 1;
+                f.tile_begin = (f.row_begin / 8) * f.tiles_x; f.tile_end = ((f.row_end + 7) / 8) * f.tiles_x;
+                HIP_TRY((hipError_t)launch_render(rt->scene, f, d_fb, nullptr, rt->bundle));
+                HIP_TRY(hipMemcpy(out_fb + (size_t)f.row_begin * width, d_fb + (size_t)f.row_begin * width,
+                                  sizeof(uint32_t) * (size_t)width * (f.row_end - f.row_begin), hipMemcpyDeviceToHost));
+            }
+            if (on_update) on_update(user, out_fb, width, height, r_lo <= r_hi ? (uint32_t)r_lo : 0u, r_lo <= r_hi ? (uint32_t)(r_hi - r_lo + 1) : 0u);   // canvas.update(), engine.rs:253
+        }
+        HIP_TRY(hipEventRecord(rt->ev1, nullptr));
+        record_launch(rt, width, height, 0, 1);
         return RRT_OK;
     });
 }

@@ -1,6 +1,6 @@
 // render_cli.cpp -- the reference's `main` (src/main.rs:17-83) over the C++ host mirror: argv[1] = .obj, hard-coded lights and camera,
 // Scene::new(W,H).draw_scene(rt), "It took ... to draw the scene"; the minifb window loop (main.rs:80-82) is replaced by writing a binary PPM.
-//   render_cli <file.obj> [out.ppm] [width height]
+//   render_cli <file.obj> [out.ppm] [width height] [--progressive]     (--progressive: the reference's 50-row chunks with an update after each, engine.rs:196-253)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -19,7 +19,10 @@ int main(int argc, char** argv) {
         Scene scene(W, H);
         scene.draw_scene(rt);                                                                                                             // first frame: uploads code, tunes the filter
         const auto t0 = std::chrono::steady_clock::now();
-        scene.draw_scene(rt);
+        bool progressive = false;
+        for (int i = 2; i < argc; i++) if (std::string(argv[i]) == "--progressive") progressive = true;
+        if (progressive) { scene.canvas.updates = 0; scene.draw_scene_progressive(rt); std::printf("canvas updates: %zu\n", scene.canvas.updates); }
+        else scene.draw_scene(rt);
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         std::printf("It took: %.2fms to draw the scene (kernel %.3f ms)\n", ms, rt.last_stats().kernel_ms);                               // main.rs:76
         std::FILE* f = std::fopen(out, "wb");

@@ -13,6 +13,7 @@
 #include <stdexcept>
 #include <string>
 #include <utility>
+#include <functional>
 #include <vector>
 
 #include "../../../include/rrt.h"
@@ -79,7 +80,10 @@ private:
 struct Canvas {                        // engine.rs:123-167 without the minifb window
     size_t width, height;
     std::vector<uint32_t> buffer;      // engine.rs:127,135: width*height, zero-initialised
+    std::function<void(const Canvas&)> on_update;   // stands in for window.update_with_buffer (engine.rs:162-166); empty = no display
+    size_t updates = 0;
     Canvas(size_t w, size_t h) : width(w), height(h), buffer(w * h, 0u) {}
+    void update() { ++updates; if (on_update) on_update(*this); }      // engine.rs:160-167
 };
 
 class Scene {                          // engine.rs:171-255
@@ -87,7 +91,16 @@ public:
     Canvas canvas;
     Scene(size_t width, size_t height) : canvas(width, height) {}       // Scene::new, engine.rs:177
     // Scene::draw_scene (engine.rs:186): one HIP launch instead of the rayon row loop; the reference consumes `rt`, here it is borrowed
-    void draw_scene(const RayTracer& rt) { check(rrt_render(rt.handle(), (uint32_t)canvas.width, (uint32_t)canvas.height, canvas.buffer.data()), "draw_scene"); }
+    void draw_scene(const RayTracer& rt) {
+        check(rrt_render(rt.handle(), (uint32_t)canvas.width, (uint32_t)canvas.height, canvas.buffer.data()), "draw_scene");
+        canvas.update();
+    }
+    // the reference's pacing (engine.rs:196-253): 50 scene rows per chunk, bottom of the canvas first, canvas.update() after every chunk
+    void draw_scene_progressive(const RayTracer& rt) {
+        check(rrt_render_progressive(rt.handle(), (uint32_t)canvas.width, (uint32_t)canvas.height, canvas.buffer.data(), 0,
+                                     [](void* user, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t) { static_cast<Canvas*>(user)->update(); }, &canvas),
+              "draw_scene_progressive");
+    }
 };
 
 // the constants `main` hard-codes (main.rs:32-67)

@@ -947,9 +947,9 @@ __global__ __launch_bounds__(64, kBundle ? RRT_WAVES_BUNDLE : RRT_WAVES_LANE) vo
     const uint32_t lane = threadIdx.x;
     const Stack stk{lds, lane};
     const uint32_t local_tile = blockIdx.x >> 2, quad = blockIdx.x & 3u;
-    const uint32_t tile = local_tile * F.world + F.rank;
+    const uint32_t tile = F.tile_begin + local_tile * F.world + F.rank;
     const uint32_t pix = lane >> 2, sub = lane & 3u;
-    const bool tile_ok = tile < F.tiles_x * F.tiles_y;
+    const bool tile_ok = tile < F.tile_end;
     const uint32_t tx = tile_ok ? tile % F.tiles_x : 0, ty = tile_ok ? tile / F.tiles_x : 0;
     const uint32_t px = tx * 8 + (quad & 1u) * 4 + (pix & 3u);
     const uint32_t py = ty * 8 + (quad >> 1) * 4 + (pix >> 2);
@@ -957,7 +957,7 @@ __global__ __launch_bounds__(64, kBundle ? RRT_WAVES_BUNDLE : RRT_WAVES_LANE) vo
     // put_pixel (engine.rs:146-158): new_x = x + W/2, new_y = H - (y + H/2); draw_scene loops x in [-W/2, W/2), y in [-H/2, H/2)
     // (engine.rs:198,205).  Pixels with no (x,y) in range stay 0 (Canvas::new, engine.rs:135): row 0 (rows 0,1 for odd H) and,
     // for odd W, the last column.  The scene row y = -H/2 maps to new_y = H and is rejected (engine.rs:152-155), so it is not traced.
-    const bool in_fb = tile_ok && (int32_t)px < W && (int32_t)py < H;
+    const bool in_fb = tile_ok && (int32_t)px < W && py >= F.row_begin && py < F.row_end;    // row_end <= height
     const bool traced = in_fb && (int32_t)px < 2 * (W / 2) && (int32_t)py >= H - 2 * (H / 2) + 1;
     const int32_t x = (int32_t)px - W / 2;
     const int32_t y = (H - H / 2) - (int32_t)py;
@@ -1038,7 +1038,7 @@ __global__ __launch_bounds__(64) void intersect_kernel(const DevScene S, uint32_
 uint32_t stack_bytes_per_wave(uint32_t levels) { return levels * kLevelBytes; }
 
 int launch_render(const DevScene& s, const FrameParams& f, uint32_t* d_out, void* stream, bool bundle) {
-    const uint32_t n_tiles = f.tiles_x * f.tiles_y;
+    const uint32_t n_tiles = f.tile_end > f.tile_begin ? f.tile_end - f.tile_begin : 0u;
     const uint32_t local_tiles = (n_tiles + f.world - 1) / f.world;
     if (local_tiles == 0) return 0;
     if (bundle) hipLaunchKernelGGL(render_kernel<true>, dim3(local_tiles * 4), dim3(64), stack_bytes_per_wave(s.stack_levels), (hipStream_t)stream, s, f, d_out);

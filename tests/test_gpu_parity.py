@@ -70,6 +70,29 @@ def test_random_rays_with_max_t_bit_exact(teapot_rt, teapot_oracle):
     assert 0.2 < hit.mean() < 0.95
 
 
+@pytest.mark.parametrize("mode", ["lane", "bundle"])
+def test_extreme_ray_magnitudes_bit_exact(rrt, teapot, teapot_oracle, mode):
+    """Rays whose components leave the range in which the walk may share one reciprocal per axis across its slab quotients (render.hip, RayRcp:
+    |d| in [2^-500, 2^500], origin components 0 or in [2^-200, 2^200]) must take the ordinary divide and still agree bit for bit: directions scaled by
+    2^+-600 (same line, t scaled the other way), denormal-small and zero origin components, in both kernel variants."""
+    rng = np.random.default_rng(11)
+    n = 600
+    o = rng.uniform([-4, 0, -6], [4, 5, 4], (n, 3)); d = rng.normal(size=(n, 3))
+    scale = np.ones(n); scale[:150] = 2.0 ** 600; scale[150:300] = 2.0 ** -600; scale[300:350] = 2.0 ** 499; scale[350:400] = 2.0 ** -499
+    d *= scale[:, None]
+    o[400:450, 0] = 1e-300; o[450:500, 1] = 5e-201 ; o[500:550, 2] = 0.0; o[550:, 0] = 2.0 ** -1060   # denormal
+    rt = rrt.RayTracer(teapot, rrt.default_lights(), box_filter=mode)
+    hit, t, u, v, tri = rt.intersect_rays(o, d)
+    n_hit = 0
+    for i in range(n):
+        rh, rt_, ru, rv, rtri = teapot_oracle.intersect(o[i], d[i])
+        assert bool(hit[i]) == rh, i
+        if rh:
+            n_hit += 1
+            assert (t[i], u[i], v[i], tri[i]) == (rt_, ru, rv, rtri), i
+    assert n_hit > 100
+
+
 def test_center_column_nan_path(teapot_rt, teapot_oracle):
     """Column w/2: d.x = 0 at origin.x = 0 == the root split plane -> (0-0)/0 = NaN in the slab test (ray.rs:22-23)."""
     w, h = 128, 96
@@ -288,3 +311,32 @@ def test_cpp_host_cli_matches_python_host(rrt, teapot_rt, tmp_path):
     rgb = np.frombuffer(raw[len(b"P6\n200 150\n255\n"):], np.uint8).reshape(150, 200, 3).astype(np.uint32)
     fb = (rgb[..., 0] << 16) | (rgb[..., 1] << 8) | rgb[..., 2]
     assert np.array_equal(fb, teapot_rt.render(200, 150))
+    out2 = tmp_path / "g.ppm"
+    r = subprocess.run([cli, os.path.join(ASSETS, "model2.obj"), str(out2), "200", "150", "--progressive"], capture_output=True, text=True)
+    assert r.returncode == 0 and "canvas updates: 3" in r.stdout, r.stdout + r.stderr          # 150 scene rows in chunks of 50 (engine.rs:195-199)
+    assert out2.read_bytes() == raw
+
+
+@pytest.mark.parametrize("w,h,chunk", [(200, 150, 50), (97, 61, 50), (64, 48, 7), (33, 2, 50), (16, 1, 50)])
+def test_progressive_draw_matches_reference_pacing(rrt, teapot_rt, w, h, chunk):
+    """rrt_render_progressive: the reference's chunked draw_scene (engine.rs:196-253).  The finished canvas equals the one-launch frame; the
+    chunks arrive bottom-up (scene rows y = -H/2 .. H/2-1 map to canvas rows H-1 .. 1), one update per chunk of `chunk` scene rows, and after
+    each update exactly the rows of the chunks so far are present."""
+    full = teapot_rt.render(w, h)
+    seen = []
+    def on_update(fb, r0, n):
+        seen.append((r0, n, fb.copy()))
+    fb = teapot_rt.render_progressive(w, h, on_update, chunk)
+    assert np.array_equal(fb, full)
+    half = h // 2
+    assert len(seen) == len(range(-half, half, chunk))                  # engine.rs:198: one canvas.update() per chunk
+    done = np.zeros(h, bool)
+    y = -half
+    for r0, n, snap in seen:
+        ys = range(y, min(y + chunk, half)); y += chunk
+        rows = sorted(r for r in (h - (yy + half) for yy in ys) if r < h)   # put_pixel rejects new_y == h (engine.rs:152-155)
+        assert (n == len(rows)) and (n == 0 or r0 == rows[0])
+        done[rows] = True
+        assert np.array_equal(snap[done], full[done]) and not snap[~done].any()
+    sc = rrt.Scene(w, h); sc.draw_scene(teapot_rt, progressive=True)
+    assert np.array_equal(sc.canvas.buffer, full) and sc.canvas.updates == len(range(-half, half, 50))   # the reference's chunk size, engine.rs:195
