@@ -340,3 +340,42 @@ def test_progressive_draw_matches_reference_pacing(rrt, teapot_rt, w, h, chunk):
         assert np.array_equal(snap[done], full[done]) and not snap[~done].any()
     sc = rrt.Scene(w, h); sc.draw_scene(teapot_rt, progressive=True)
     assert np.array_equal(sc.canvas.buffer, full) and sc.canvas.updates == len(range(-half, half, 50))   # the reference's chunk size, engine.rs:195
+
+
+@pytest.mark.parametrize("mode", ["lane", "bundle", "no_cull"])
+def test_deep_octree_rays_bit_exact(rrt, ob, mode):
+    """Clusters of many tiny triangles a hair apart: a leaf splits whenever a second triangle arrives (octree.rs:79-92), so the tree goes ~20 levels deep
+    before it separates them -- long LDS stacks, long unwinds, leaf children at every level.  Rays aimed at the triangles (and just past them) must
+    return the oracle's (hit, t, u, v, triangle) bit for bit in every kernel variant."""
+    rng = np.random.default_rng(21)
+    tris = []
+    for k in range(6):                                           # (every arrival in an occupied leaf adds one level: the resident stays, octree.rs:82-104)
+        c = rng.uniform([-2.5, 0.5, 1], [2.5, 4, 6]); size = 10.0 ** rng.uniform(-6.5, -4)
+        for j in range(40):
+            q = c + rng.normal(size=3) * size * 6.0
+            tris.append([q + np.array([-0.5, -0.4, 0.0]) * size, q + np.array([0.5, -0.4, 0.03]) * size, q + np.array([0.0, 0.5, 0.01]) * size])
+    tris.append([(-6, -1, 8), (6, -1, 8), (0, 6, 8.5)])
+    tris = np.array(tris, np.float64); n = len(tris)
+    uv = np.tile([[0.1, 0.2, 0], [0.9, 0.1, 0], [0.5, 0.8, 0]], (n, 1, 1)).astype(np.float64); nrm = np.tile([0.0, 0.1, -1.0], (n, 3, 1))
+    mats = [dict(ka=(1, 1, 1), kd=(1, 1, 1), ks=(1, 1, 1), ns=240.0, kr=0.0, tex=0, bump=-1)]
+    tex = [np.arange(48, dtype=np.uint8).reshape(4, 4, 3)]
+    sd = rrt.SceneData.from_arrays(tris, uv, nrm, np.zeros(n, np.uint32), mats, tex)
+    assert sd.info["max_depth"] >= 18, sd.info
+    lights = rrt.default_lights()
+    osc = ob.OracleScene(tris, uv, nrm, np.zeros(n, np.uint32), mats, tex, [(l.kind, l.intensity, (l.v.x, l.v.y, l.v.z)) for l in lights], (0, 2, -10))
+    cam = np.array([0.0, 2.0, -10.0])
+    cen = tris[:-1].mean(1)
+    ext = np.abs(tris[:-1] - cen[:, None, :]).max((1, 2))
+    targets = np.concatenate([cen, cen + rng.normal(size=cen.shape) * ext[:, None] * 0.6, cen + rng.normal(size=cen.shape) * ext[:, None] * 3.0])
+    o = np.tile(cam, (len(targets), 1)); d = targets - cam
+    rt = rrt.RayTracer(sd, lights, no_cull=True) if mode == "no_cull" else rrt.RayTracer(sd, lights, box_filter=mode)
+    hit, t, u, v, tri = rt.intersect_rays(o, d)
+    small = 0
+    for i in range(len(targets)):
+        rh, rt_, ru, rv, rtri = osc.intersect(o[i], d[i])
+        assert bool(hit[i]) == rh, i
+        if rh:
+            assert (t[i], u[i], v[i], tri[i]) == (rt_, ru, rv, rtri), i
+            small += rtri != n - 1
+    assert small > 100                                           # the tiny triangles in the deep leaves are really being hit
+    assert_frame_close(rt.render(64, 48), osc.render(64, 48)[0], "deep-octree frame")
