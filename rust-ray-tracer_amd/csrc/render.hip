@@ -268,7 +268,11 @@ __device__ __forceinline__ bool slab32(const UBox& b, const Ray32& r) {
 struct Prof { unsigned long long c[16]; unsigned long long t[8]; unsigned long long last; };
 #define PROF_DECL Prof& prof,
 #define PROF_ARG prof,
+#ifdef RRT_PROF_HIST   /* histogram build: only the histogram counters (written as 100 + index) count */
+#define PROF_ADD(i, x) ((i) >= 100 ? (void)(prof.c[(i) >= 100 ? (i) - 100 : 0] += (unsigned long long)(x)) : (void)0)
+#else
 #define PROF_ADD(i, x) (prof.c[i] += (unsigned long long)(x))
+#endif
 #define PROF_T(i) do { const unsigned long long _n = __builtin_amdgcn_s_memtime(); prof.t[i] += _n - prof.last; prof.last = _n; } while (0)
 #else
 #define PROF_DECL
@@ -417,6 +421,9 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
         PROF_ADD(0, 1); PROF_ADD(1, __popcll(__ballot(!done && cur == unode)));
         PROF_T(0);                                                       // [0] pick node + node record load
         const bool mine = !done && cur == unode;
+#ifdef RRT_PROF_HIST   /* developer histogram of lanes parked at the visited node (tools/visit_hist.py) */
+        { const int pc = __popcll(__ballot(mine)); PROF_ADD(100 + (pc <= 1 ? 0 : pc <= 3 ? 1 : pc <= 7 ? 2 : pc <= 15 ? 3 : pc <= 31 ? 4 : 5), 1); PROF_ADD(100 + (fc != 0 ? 6 : 7), 1); PROF_ADD(108, pc); }
+#endif
         uint32_t order = 0, nchild = 0;
         uint32_t leaf_hit = 0;                                           // bit k: child k is a leaf whose triangle this lane's ray hits
         if (mine && (fl & 0x100u)) {
