@@ -8,7 +8,7 @@ for lib in "$@"; do
   tag=$(basename $lib .so)
   OUT=$ROOT/gpurun_out/pmcab_$tag
   rm -rf $OUT; mkdir -p $OUT
-  RRT_LIB=$ROOT/$lib timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES --output-format csv -d $OUT/pmc_sq -- python3 $ROOT/bench.py --no-cpu-baseline --steps 30 --warmup 3 > $OUT/log 2>&1
+  RRT_LIB=$ROOT/$lib timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVE_CYCLES --output-format csv -d $OUT/pmc_sq -- python3 $ROOT/bench.py --no-cpu-baseline ${BENCH_ARGS:---steps 30 --warmup 3} > $OUT/log 2>&1
   python3 - "$OUT" "$tag" <<'PY'
 import csv, glob, sys, collections
 out, tag = sys.argv[1], sys.argv[2]
