@@ -42,7 +42,7 @@ def main() -> None:
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scene", default=os.path.join(ROOT, "assets", "model2.obj"))
-    ap.add_argument("--pipeline-depth", type=int, default=2, help="N > 1: frames in flight (gather + de-tiling of a frame overlap the tracing of the next); 1 = none")
+    ap.add_argument("--pipeline-depth", type=int, default=4, help="N > 1: frames in flight (gather + de-tiling of a frame overlap the tracing of the next); 1 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the bounded cpu_baseline sample")
     args = ap.parse_args()
@@ -103,6 +103,9 @@ def main() -> None:
         # final gather to GPU 0 (BASELINE.json north_star): grouped point-to-point sends, every peer on its own xGMI link -- not a ring
         chunks = [[g[i * tpr * 64:(i + 1) * tpr * 64] for i in range(world)] if rank == 0 else None for g in gathered]
         side = torch.cuda.Stream() if (rank == 0 and not rehearsal) else None       # de-tiling stream of GPU 0
+        # each slot traces on its own stream: the next frame's waves fill the slots that the tail of the previous frame's launch leaves idle
+        # (at N = 8 a rank's launch is only ~4 waves per wave slot deep)
+        trace_streams = [torch.cuda.Stream() if not rehearsal else torch.cuda.current_stream() for _ in range(DEPTH)]
         gather_work = [None] * DEPTH                                                # outstanding gather of each slot
         detile_done = [torch.cuda.Event() for _ in range(DEPTH)]                    # slot's gather buffer has been de-tiled (GPU 0)
         detile_pending = [False] * DEPTH
@@ -112,7 +115,7 @@ def main() -> None:
     if not multi:
         launch_frame = rt.bind_render(fb, W, H)
     else:
-        launch_tiles = [rt.bind_render_tiles(m, W, H, rank, world) for m in mine]
+        launch_tiles = [rt.bind_render_tiles(m, W, H, rank, world, stream=ts.cuda_stream) for m, ts in zip(mine, trace_streams)]
         launch_detile = [rt.bind_detile(g, fb, W, H, world, stream=(side.cuda_stream if side is not None else None)) for g in gathered] if rank == 0 else None
     frame_no = [0]
 
@@ -123,14 +126,16 @@ def main() -> None:
             if i is not None: ev[i][1].record()
             return
         b = frame_no[0] % DEPTH; frame_no[0] += 1
-        if gather_work[b] is not None:
-            gather_work[b].wait()                            # the slot's previous gather has read mine[b] (orders the current stream after it; host does not block on RCCL)
-        if rank == 0 and detile_pending[b]:
-            torch.cuda.current_stream().wait_event(detile_done[b])   # ... and its gather buffer has been consumed before the next gather (issued after this point) overwrites it
-        if i is not None: ev[i][0].record()
-        launch_tiles[b]()
-        if i is not None: ev[i][1].record()
-        gather_work[b] = dist.gather(mine[b], chunks[b], dst=0, async_op=True)
+        ts = trace_streams[b]
+        with torch.cuda.stream(ts):
+            if gather_work[b] is not None:
+                gather_work[b].wait()                        # the slot's previous gather has read mine[b] (orders the slot's stream after it; the host does not block on RCCL)
+            if rank == 0 and detile_pending[b]:
+                ts.wait_event(detile_done[b])                # ... and its gather buffer has been consumed before the next gather (issued after this point) overwrites it
+            if i is not None: ev[i][0].record(ts)
+            launch_tiles[b]()
+            if i is not None: ev[i][1].record(ts)
+            gather_work[b] = dist.gather(mine[b], chunks[b], dst=0, async_op=True)   # RCCL's stream waits for the slot's stream
         if rank == 0:
             if side is None:                                 # rehearsal (gloo): synchronous
                 gather_work[b].wait(); gather_work[b] = None
@@ -149,6 +154,7 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    torch.cuda.synchronize()                                 # buffers were zero-filled on the default stream; the slots run on their own
     for _ in range(args.warmup):
         step(None)
     fence()
@@ -261,7 +267,7 @@ def main() -> None:
                "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "reference scene assets/model2.obj (teapot+table+mirror, 6334 triangles), camera/lights of main.rs"
                if os.path.basename(args.scene) == "model2.obj" else "synthetic",
                "config": {"workload": f"{os.path.basename(args.scene)} {W}x{H}, 4 sub-samples/pixel, shadow rays + depth-5 mirror reflection, f64",
-                          "rays_primary_per_frame": rays_primary, "partition": "single launch" if world == 1 else f"8x8-pixel tiles round-robin over {world} GPUs + RCCL gather to GPU 0, {DEPTH} frames in flight",
+                          "rays_primary_per_frame": rays_primary, "partition": "single launch" if world == 1 else f"8x8-pixel tiles round-robin over {world} GPUs + RCCL gather to GPU 0, {DEPTH} frames in flight (one stream per slot)",
                           "octree_nodes": sd.info["n_nodes"], "triangles": sd.info["n_tris"]},
                "frame_ms": round(ms_per_step, 4), "kernel_ms": round(kernel_ms, 4), **({"rehearsal": "gloo on one GPU: NOT a benchmark result"} if rehearsal else {}),
                "frame_checksum": int(np.bitwise_xor.reduce(frame.ravel().astype(np.uint64) * np.arange(1, frame.size + 1, dtype=np.uint64)))}
