@@ -118,6 +118,8 @@ def main() -> None:
         launch_tiles = [rt.bind_render_tiles(m, W, H, rank, world, stream=ts.cuda_stream) for m, ts in zip(mine, trace_streams)]
         launch_detile = [rt.bind_detile(g, fb, W, H, world, stream=(side.cuda_stream if side is not None else None)) for g in gathered] if rank == 0 else None
     frame_no = [0]
+    set_stream = torch.cuda.set_stream
+    default_stream = torch.cuda.current_stream()
 
     def step(i: int | None) -> None:
         if not multi:
@@ -127,27 +129,28 @@ def main() -> None:
             return
         b = frame_no[0] % DEPTH; frame_no[0] += 1
         ts = trace_streams[b]
-        with torch.cuda.stream(ts):
-            if gather_work[b] is not None:
-                gather_work[b].wait()                        # the slot's previous gather has read mine[b] (orders the slot's stream after it; the host does not block on RCCL)
-            if rank == 0 and detile_pending[b]:
-                ts.wait_event(detile_done[b])                # ... and its gather buffer has been consumed before the next gather (issued after this point) overwrites it
-            if i is not None: ev[i][0].record(ts)
-            launch_tiles[b]()
-            if i is not None: ev[i][1].record(ts)
-            gather_work[b] = dist.gather(mine[b], chunks[b], dst=0, async_op=True)   # RCCL's stream waits for the slot's stream
+        set_stream(ts)                                       # (torch.cuda.set_stream, not the context manager: the host side of a step is on the critical path at N = 8)
+        if gather_work[b] is not None:
+            gather_work[b].wait()                            # the slot's previous gather has read mine[b] (orders the slot's stream after it; the host does not block on RCCL)
+        if rank == 0 and detile_pending[b]:
+            ts.wait_event(detile_done[b])                    # ... and its gather buffer has been consumed before the next gather (issued after this point) overwrites it
+        if i is not None: ev[i][0].record(ts)
+        launch_tiles[b]()
+        if i is not None: ev[i][1].record(ts)
+        gather_work[b] = dist.gather(mine[b], chunks[b], dst=0, async_op=True)   # RCCL's stream waits for the slot's stream
         if rank == 0:
             if side is None:                                 # rehearsal (gloo): synchronous
                 gather_work[b].wait(); gather_work[b] = None
                 launch_detile[b]()
             else:
-                with torch.cuda.stream(side):
-                    gather_work[b].wait()                    # side stream waits for the gather; the tracing stream goes on with the next frame
-                    launch_detile[b]()
-                    detile_done[b].record(side); detile_pending[b] = True
+                set_stream(side)
+                gather_work[b].wait()                        # side stream waits for the gather; the tracing streams go on with the next frames
+                launch_detile[b]()
+                detile_done[b].record(side); detile_pending[b] = True
 
     def fence() -> None:
         if multi:
+            set_stream(default_stream)
             for w in gather_work:
                 if w is not None: w.wait()
             torch.cuda.synchronize()
@@ -161,6 +164,7 @@ def main() -> None:
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    host_enqueue_ms = (time.perf_counter() - t0) / args.steps * 1e3   # host time to issue one step (launch + gather + de-tile calls), before any waiting
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -269,7 +273,7 @@ def main() -> None:
                "config": {"workload": f"{os.path.basename(args.scene)} {W}x{H}, 4 sub-samples/pixel, shadow rays + depth-5 mirror reflection, f64",
                           "rays_primary_per_frame": rays_primary, "partition": "single launch" if world == 1 else f"8x8-pixel tiles round-robin over {world} GPUs + RCCL gather to GPU 0, {DEPTH} frames in flight (one stream per slot)",
                           "octree_nodes": sd.info["n_nodes"], "triangles": sd.info["n_tris"]},
-               "frame_ms": round(ms_per_step, 4), "kernel_ms": round(kernel_ms, 4), **({"rehearsal": "gloo on one GPU: NOT a benchmark result"} if rehearsal else {}),
+               "frame_ms": round(ms_per_step, 4), "kernel_ms": round(kernel_ms, 4), "host_enqueue_ms_per_step": round(host_enqueue_ms, 4), **({"rehearsal": "gloo on one GPU: NOT a benchmark result"} if rehearsal else {}),
                "frame_checksum": int(np.bitwise_xor.reduce(frame.ravel().astype(np.uint64) * np.arange(1, frame.size + 1, dtype=np.uint64)))}
         if roofline is not None:
             out["roofline"] = roofline
