@@ -213,7 +213,8 @@ def main() -> None:
             cpu_rays = cnt["rays_primary"]
             cpu = {"value": round(cpu_rays / cpu_s / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
                    "sample": f"oracle (f64 C restatement of the reference rayon path, -O3 -ffp-contract=off) rendering {os.path.basename(args.scene)} at {sw}x{sh} "
-                             f"({cpu_rays} primary rays incl. the discarded row) in {cpu_s:.2f} s on {cores} threads",
+                             f"({cpu_rays} primary rays incl. the discarded row) in {cpu_s:.2f} s on {cores} threads; parallel over the rows of one 50-row chunk at a time "
+                             f"with a barrier per chunk, as the reference's rayon loop (engine.rs:196-203), so at most 50 threads are busy at once",
                    "frame_ms_at_sample": round(cpu_s * 1e3, 1)}
             if div == 1:
                 d = np.abs(np.stack([(frame >> s) & 255 for s in (16, 8, 0)], -1).astype(np.int64) - np.stack([(ref >> s) & 255 for s in (16, 8, 0)], -1).astype(np.int64))
