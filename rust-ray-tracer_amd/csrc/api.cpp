@@ -69,6 +69,13 @@ void validate_model(const Model& m) {
     for (auto& mat : m.materials) {
         if (mat.tex < 0 || (size_t)mat.tex >= m.textures.size()) throw Error{RRT_ERR_INVALID_ARG, "material texture index out of range"};
         if (mat.bump >= (int32_t)m.textures.size()) throw Error{RRT_ERR_INVALID_ARG, "material bump index out of range"};
+        if (mat.bump >= 0) {
+            // The bump texel is addressed with the COLOUR texture's (x, y) and the bump map's width (raytracer.rs:127-128).  Where that index can
+            // leave the bump map the reference panics on the first such hit; on the GPU it would be a wild read, so the scene is refused up front.
+            const Texture& t = m.textures[mat.tex]; const Texture& b = m.textures[mat.bump];
+            if ((uint64_t)b.width * (t.height - 1) + (t.width - 1) >= (uint64_t)b.width * b.height)
+                throw Error{RRT_ERR_INVALID_ARG, "bump map too small for the texture whose texel indices address it (raytracer.rs:127-128 would index out of bounds)"};
+        }
     }
     for (auto& t : m.triangles) if (t.mat >= m.materials.size()) throw Error{RRT_ERR_INVALID_ARG, "triangle material index out of range"};
 }
