@@ -388,6 +388,7 @@ int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n
         S.child_boxes = upload(rt.get(), CS.child_boxes.data(), CS.child_boxes.size());
         S.tboxes = upload(rt.get(), CS.tboxes.data(), CS.tboxes.size());
         S.cull_enabled = (o.flags & RRT_FLAG_NO_CULL) ? 0u : 1u;
+        S.has_groups = CS.has_groups ? 1u : 0u;
         S.bounds_plain = 1u;
         for (const DevNode& d : nodes)
             for (int k = 0; k < 3; k++)

@@ -20,6 +20,8 @@ namespace {
 
 constexpr uint32_t kClusterTris = 8;
 constexpr uint32_t kSuperClusters = 8;
+constexpr size_t kGroupSupers = 8;          // super-clusters per group record
+constexpr size_t kGroupThreshold = 24;      // lists with more super-clusters than this get group records
 constexpr double kPadFraction = 1.0 / 32768.0;   // 2^-15 of the scene magnitude
 
 struct TriBox { double lo[3], hi[3], c[3]; };
@@ -93,6 +95,7 @@ void build_clusters(const Model& m, bool enable_cull, ClusterSet& out) {
         std::vector<std::pair<size_t, size_t>> sup_ranges;
         if (enable_cull) split(items, 0, n, (size_t)kClusterTris * kSuperClusters, boxes, sup_ranges);
         else for (size_t s0 = 0; s0 < n; s0 += (size_t)kClusterTris * kSuperClusters) sup_ranges.emplace_back(s0, std::min<size_t>(n, s0 + kClusterTris * kSuperClusters));   // list order
+        const size_t node_first_super = out.supers.size();
         for (auto [sb, se] : sup_ranges) {
             std::vector<std::pair<size_t, size_t>> cl_ranges;
             if (enable_cull) split(items, sb, se, kClusterTris, boxes, cl_ranges);
@@ -134,6 +137,25 @@ void build_clusters(const Model& m, bool enable_cull, ClusterSet& out) {
                 out.tboxes.push_back(TB);
             }
             out.supers.push_back(S);
+        }
+        // A long list (the root of a large soup holds thousands of straddlers) gets one more level: every run of kGroupSupers consecutive
+        // super-clusters -- spatially compact, they come out of the median splits in order -- is preceded by a GROUP record (tri_count = 0,
+        // tri_begin = number of super-clusters it covers) carrying the union of their boxes.  The lane-filter kernel skips a group no lane can
+        // reach; the bundle-filter kernel ignores group records.
+        const size_t n_sup = out.supers.size() - node_first_super;
+        if (enable_cull && n_sup > kGroupThreshold) {
+            out.has_groups = true;
+            std::vector<DevSuper> plain(out.supers.begin() + node_first_super, out.supers.end());
+            out.supers.resize(node_first_super);
+            for (size_t g0 = 0; g0 < plain.size(); g0 += kGroupSupers) {
+                const size_t g1 = std::min(plain.size(), g0 + kGroupSupers);
+                DevSuper G{};
+                for (int k = 0; k < 3; k++) { G.lo[k] = FLT_MAX; G.hi[k] = -FLT_MAX; }
+                for (size_t i = g0; i < g1; i++) for (int k = 0; k < 3; k++) { G.lo[k] = std::min(G.lo[k], plain[i].lo[k]); G.hi[k] = std::max(G.hi[k], plain[i].hi[k]); }
+                G.tri_begin = (uint32_t)(g1 - g0); G.tri_count = 0;
+                out.supers.push_back(G);
+                out.supers.insert(out.supers.end(), plain.begin() + g0, plain.begin() + g1);
+            }
         }
         out.node_sup_count[node] = (uint32_t)out.supers.size() - out.node_sup_begin[node];
     }

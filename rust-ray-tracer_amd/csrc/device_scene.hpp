@@ -70,6 +70,7 @@ struct DevScene {                // passed to kernels by value (kernarg segment 
     double surface_offset;
     float cull_limit;            // rays with |origin| or |direction| components beyond this (or non-finite) skip the box culling
     uint32_t cull_enabled;
+    uint32_t has_groups;         // some own list carries group records (clusters.cpp): launches use the kernel instantiation that handles them
     uint32_t bounds_plain;       // every node plane (lo, mid, hi) is 0 or has magnitude in [2^-200, 2^200]: the walk may share the reciprocal of a ray's direction across its slab quotients (render.hip, RayRcp)
     DevLight lights[RRT_MAX_LIGHTS];
 #ifdef RRT_PROFILE
@@ -109,6 +110,7 @@ struct ClusterSet {
     std::vector<uint32_t> slot_tri, slot_pos;          // per device slot: triangle index in push order (kPadSlot for padding), position in its node's own list
     std::vector<uint32_t> node_sup_begin, node_sup_count;
     std::vector<uint32_t> node_leaf_slot;              // slot of the triangle of a single-triangle leaf that is tested at its parent (kPadSlot otherwise)
+    bool has_groups = false;                           // some list got group records
     bool inline_leaves = false;                        // single-triangle leaves are tested at their parents (node_leaf_slot, DevNode::leaf_base)
     uint32_t n_list_slots = 0;                         // slots [0, n_list_slots) belong to own lists (cboxes/tboxes cover these); leaf slots follow
     double scene_magnitude = 0;

@@ -383,7 +383,7 @@ __device__ __forceinline__ uint32_t lane_read(uint32_t v, uint32_t src_lane) { r
 // any_ok: the caller only uses Some/None of the result (shadow query, raytracer.rs:181-187).
 // kBundle selects the own-list filter: false = every lane tests each box against its own ray (64 rays x 1 box per instruction);
 // true = boxes in lanes against the wave's ray bundle (64 boxes x 1 bundle per instruction).  Same results either way.
-template <bool kBundle>
+template <bool kBundle, bool kGroups>
 __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stack& stk, bool active, bool any_ok, V3 o, V3 d, double max_t,
                                          double& out_t, uint32_t& out_slot) {
     constexpr bool kLeaf = !kBundle;   // leaf children are tested at their parent by the lane-filter kernel only (measured: the extra code costs the bundle kernel 12 % on the teapot)
@@ -581,7 +581,8 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                     bool h = false; uint32_t tb = 0, tn = 0;
                     if (si < sc) {
                         const DevSuper* P = S.supers + sb + si;
-                        h = bundle_hit(BU, P->lo[0], P->lo[1], P->lo[2], P->hi[0], P->hi[1], P->hi[2]); tb = P->tri_begin; tn = P->tri_count;
+                        tb = P->tri_begin; tn = P->tri_count;
+                        h = (!kGroups || tn != 0u) && bundle_hit(BU, P->lo[0], P->lo[1], P->lo[2], P->hi[0], P->hi[1], P->hi[2]);   // (tn == 0: a group record, clusters.cpp -- the lane-filter kernel's business)
                     }
                     PROF_ADD(10, 1);
                     n1 = wave_compact2(h, tb, tn, lane, l1a, l1b);
@@ -636,6 +637,17 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                     const bool hs = (sc == 1) || slab32(SP, r32);
                     const uint32_t tb = SP.a, tn = SP.b;
                     PROF_ADD(10, 1);
+                    if constexpr (kGroups) {
+                        if (sc > 1 && tn == 0u) {
+                            // a group record (clusters.cpp): the box of the next `tb` super-clusters; if no lane can reach it they are all skipped
+                            if (__builtin_amdgcn_ballot_w64(hs) == 0ull) {
+                                si += tb;
+                                if (si + 1 < sc) SN = load_ubox(supers + sb + si + 1);
+                            }
+                            SP = SN;
+                            continue;
+                        }
+                    }
                     if (__builtin_amdgcn_ballot_w64(hs) != 0ull) {
                         // the (up to) 8 cluster boxes of this super-cluster in bursts of 4; cluster c covers slots tb+8c .. tb+8c+7
                         const RRT_CONSTANT u32x16* cb = (const RRT_CONSTANT u32x16*)(cboxes + (tb >> 3));
@@ -801,7 +813,7 @@ __device__ __forceinline__ V3 specular_term(double sw, double intensity, V3 norm
 }
 
 // RayTracer::get_ray_colour (raytracer.rs:29-112) for 64 lanes; wave-uniform call.  Returns 0x00RRGGBB.
-template <bool kBundle>
+template <bool kBundle, bool kGroups>
 __device__ __forceinline__ uint32_t trace_colour(PROF_DECL const DevScene& S, const Stack& stk, bool active, V3 origin, V3 direction) {
     bool live = active;
     bool in_shadow = false;                 // false: the ray in flight is a segment (primary/reflection) ray; true: a shadow ray
@@ -816,7 +828,7 @@ __device__ __forceinline__ uint32_t trace_colour(PROF_DECL const DevScene& S, co
     while (__any(live)) {
         double t; uint32_t slot;
         PROF_T(4);                                                       // [4] shading / state machine between traversals
-        traverse<kBundle>(PROF_ARG S, stk, live, in_shadow, ro, rd, rmax, t, slot);
+        traverse<kBundle, kGroups>(PROF_ARG S, stk, live, in_shadow, ro, rd, rmax, t, slot);
         if (live) {
             const bool found = slot != kNone;
             if (!in_shadow) {
@@ -948,7 +960,7 @@ __device__ __forceinline__ uint32_t trace_colour(PROF_DECL const DevScene& S, co
 #ifndef RRT_WAVES_BUNDLE
 #define RRT_WAVES_BUNDLE 4
 #endif
-template <bool kBundle>
+template <bool kBundle, bool kGroups>
 __global__ __launch_bounds__(64, kBundle ? RRT_WAVES_BUNDLE : RRT_WAVES_LANE) void render_kernel(const DevScene S, const FrameParams F, uint32_t* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const uint32_t lane = threadIdx.x;
@@ -974,7 +986,7 @@ __global__ __launch_bounds__(64, kBundle ? RRT_WAVES_BUNDLE : RRT_WAVES_LANE) vo
 #ifdef RRT_PROFILE
     Prof prof{}; prof.last = __builtin_amdgcn_s_memtime();
 #endif
-    const uint32_t c = trace_colour<kBundle>(PROF_ARG S, stk, traced, ld3(S.origin), dir);
+    const uint32_t c = trace_colour<kBundle, kGroups>(PROF_ARG S, stk, traced, ld3(S.origin), dir);
 #ifdef RRT_PROFILE
     PROF_T(4);
     if (lane == 0) { for (int i = 0; i < 16; i++) if (prof.c[i]) atomicAdd(S.prof + i, prof.c[i]); for (int i = 0; i < 8; i++) if (prof.t[i]) atomicAdd(S.prof + 16 + i, prof.t[i]); }
@@ -1014,7 +1026,7 @@ __global__ __launch_bounds__(64) void ray_colour_kernel(const DevScene S, uint32
 #ifdef RRT_PROFILE
     Prof prof{}; prof.last = 0;
 #endif
-    const uint32_t c = trace_colour<kBundle>(PROF_ARG S, stk, ok, o, d);
+    const uint32_t c = trace_colour<kBundle, true>(PROF_ARG S, stk, ok, o, d);
     if (ok) colours[i] = c;
 }
 
@@ -1032,7 +1044,7 @@ __global__ __launch_bounds__(64) void intersect_kernel(const DevScene S, uint32_
 #ifdef RRT_PROFILE
     Prof prof{}; prof.last = 0;
 #endif
-    traverse<kBundle>(PROF_ARG S, stk, ok, false, o, d, mt, t, slot);
+    traverse<kBundle, true>(PROF_ARG S, stk, ok, false, o, d, mt, t, slot);
     if (!ok) return;
     if (slot == kNone) { hit[i] = 0; t_out[i] = 0; u_out[i] = 0; v_out[i] = 0; tri_out[i] = kNone; return; }
     double t2, u = 0, v = 0;
@@ -1048,8 +1060,14 @@ int launch_render(const DevScene& s, const FrameParams& f, uint32_t* d_out, void
     const uint32_t n_tiles = f.tile_end > f.tile_begin ? f.tile_end - f.tile_begin : 0u;
     const uint32_t local_tiles = (n_tiles + f.world - 1) / f.world;
     if (local_tiles == 0) return 0;
-    if (bundle) hipLaunchKernelGGL(render_kernel<true>, dim3(local_tiles * 4), dim3(64), stack_bytes_per_wave(s.stack_levels), (hipStream_t)stream, s, f, d_out);
-    else hipLaunchKernelGGL(render_kernel<false>, dim3(local_tiles * 4), dim3(64), stack_bytes_per_wave(s.stack_levels), (hipStream_t)stream, s, f, d_out);
+    // (four instantiations: the group-record handling of long own lists, clusters.cpp, is compiled in only for scenes that have such lists --
+    // its few instructions in the super-cluster loop cost the other scenes 5 % through register allocation alone, measured)
+    const dim3 grid(local_tiles * 4), block(64);
+    const uint32_t lds = stack_bytes_per_wave(s.stack_levels);
+    if (bundle && s.has_groups) hipLaunchKernelGGL((render_kernel<true, true>), grid, block, lds, (hipStream_t)stream, s, f, d_out);
+    else if (bundle) hipLaunchKernelGGL((render_kernel<true, false>), grid, block, lds, (hipStream_t)stream, s, f, d_out);
+    else if (s.has_groups) hipLaunchKernelGGL((render_kernel<false, true>), grid, block, lds, (hipStream_t)stream, s, f, d_out);
+    else hipLaunchKernelGGL((render_kernel<false, false>), grid, block, lds, (hipStream_t)stream, s, f, d_out);
     return (int)hipGetLastError();
 }
 

@@ -379,3 +379,38 @@ def test_deep_octree_rays_bit_exact(rrt, ob, mode):
             small += rtri != n - 1
     assert small > 100                                           # the tiny triangles in the deep leaves are really being hit
     assert_frame_close(rt.render(64, 48), osc.render(64, 48)[0], "deep-octree frame")
+
+
+def test_long_own_list_with_group_records(rrt, ob):
+    """A node whose own list exceeds 24 super-clusters gets group records (clusters.cpp): 2600 small triangles that all straddle the root's x = 0 or
+    y = 0 split plane stay in the root list (octree.rs:82-104).  Lane filter (skips groups), bundle filter (ignores group records) and the
+    reference-order mode (no index at all) must give the oracle's frame and the oracle's hits."""
+    rng = np.random.default_rng(33)
+    n = 2600
+    c = np.stack([np.zeros(n), rng.uniform(0.3, 4.5, n), rng.uniform(-2.0, 7.0, n)], -1)
+    c[n // 2:, 0] = rng.uniform(-4.0, 4.0, n - n // 2); c[n // 2:, 1] = 0.0                      # second half: across the plane y = 0
+    off = rng.uniform(-0.06, 0.06, (n, 3, 3))
+    off[: n // 2, 0, 0] = -0.05; off[: n // 2, 1, 0] = 0.05                                       # make sure the box really crosses the plane
+    off[n // 2:, 0, 1] = -0.05; off[n // 2:, 1, 1] = 0.05
+    tris = c[:, None, :] + off
+    uv = rng.random((n, 3, 3)); nrm = np.tile([0.0, 0.3, -1.0], (n, 3, 1))
+    mats = [dict(ka=(1, 1, 1), kd=(1, 1, 1), ks=(1, 1, 1), ns=50.0, kr=0.0, tex=0, bump=-1)]
+    tex = [rng.integers(0, 256, (8, 8, 3), dtype=np.uint8)]
+    sd = rrt.SceneData.from_arrays(tris, uv, nrm, np.zeros(n, np.uint32), mats, tex)
+    assert sd.info["root_own_count"] > 24 * 64, sd.info
+    lights = rrt.default_lights()
+    osc = ob.OracleScene(tris, uv, nrm, np.zeros(n, np.uint32), mats, tex, [(l.kind, l.intensity, (l.v.x, l.v.y, l.v.z)) for l in lights], (0, 2, -10))
+    ref, _ = osc.render(160, 120)
+    assert ((ref != 0xFFFFFF) & (ref != 0)).mean() > 0.02
+    exact = rrt.RayTracer(sd, lights, no_cull=True).render(160, 120)
+    assert_frame_close(exact, ref, "long list, reference order")
+    for mode in ("lane", "bundle", None):
+        assert np.array_equal(rrt.RayTracer(sd, lights, box_filter=mode).render(160, 120), exact), mode
+    cam = np.array([0.0, 2.0, -10.0])
+    tgt = tris.mean(1)[::7] + rng.normal(size=(len(tris[::7]), 3)) * 0.02
+    o = np.tile(cam, (len(tgt), 1)); d = tgt - cam
+    hit, t, u, v, tri = rrt.RayTracer(sd, lights, box_filter="lane").intersect_rays(o, d)
+    for i in range(len(tgt)):
+        rh, rt_, ru, rv, rtri = osc.intersect(o[i], d[i])
+        assert bool(hit[i]) == rh and (not rh or (t[i], u[i], v[i], tri[i]) == (rt_, ru, rv, rtri)), i
+    assert hit.mean() > 0.5
