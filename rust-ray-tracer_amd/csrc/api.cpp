@@ -369,16 +369,17 @@ int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n
             a.nrm[6] = t.n3.x; a.nrm[7] = t.n3.y; a.nrm[8] = t.n3.z;
             a.mat = t.mat; a.orig = CS.slot_tri[s];
         }
+        std::vector<DevTexture> texs(M.textures.size());
+        for (size_t i = 0; i < texs.size(); i++) {
+            texs[i].rgb = upload(rt.get(), M.textures[i].rgb.data(), M.textures[i].rgb.size());
+            texs[i].width = M.textures[i].width; texs[i].height = M.textures[i].height;
+        }
         std::vector<DevMaterial> mats(M.materials.size());
         for (size_t i = 0; i < mats.size(); i++) {
             const rrt_material& s = M.materials[i]; DevMaterial& d = mats[i];
             d.ka[0] = s.ka.x; d.ka[1] = s.ka.y; d.ka[2] = s.ka.z; d.kd[0] = s.kd.x; d.kd[1] = s.kd.y; d.kd[2] = s.kd.z;
             d.ks[0] = s.ks.x; d.ks[1] = s.ks.y; d.ks[2] = s.ks.z; d.ns = s.ns; d.kr = s.kr; d.tex = s.tex; d.bump = s.bump;
-        }
-        std::vector<DevTexture> texs(M.textures.size());
-        for (size_t i = 0; i < texs.size(); i++) {
-            texs[i].rgb = upload(rt.get(), M.textures[i].rgb.data(), M.textures[i].rgb.size());
-            texs[i].width = M.textures[i].width; texs[i].height = M.textures[i].height;
+            d.tex_desc = texs[s.tex]; d.bump_desc = s.bump >= 0 ? texs[s.bump] : DevTexture{nullptr, 0, 0};
         }
         DevScene& S = rt->scene;
         S.nodes = upload(rt.get(), nodes.data(), nodes.size());

@@ -46,8 +46,9 @@ struct DevTriAttr {                                                // 128 B: one
 };
 static_assert(sizeof(DevTriAttr) == 128, "DevTriAttr must be 128 bytes");
 
-struct DevMaterial { double ka[3], kd[3], ks[3], ns, kr; int32_t tex, bump; };   // material.rs:11-22
 struct DevTexture { const uint8_t* rgb; uint32_t width, height; };               // entities.rs:86-91
+// material.rs:11-22, with the descriptors of its texture and bump map inline: a hit reads material -> texel, not material -> texture table -> texel
+struct DevMaterial { double ka[3], kd[3], ks[3], ns, kr; int32_t tex, bump; DevTexture tex_desc, bump_desc; };
 struct DevLight { uint32_t kind, _pad; double intensity; double v[3]; };         // entities.rs:5-9
 
 #define RRT_MAX_LIGHTS 16

@@ -844,7 +844,7 @@ __device__ __forceinline__ uint32_t trace_colour(PROF_DECL const DevScene& S, co
                     p = ro + rd * t;                                                     // raytracer.rs:39
                     mat = A.mat;
                     const DevMaterial& M = S.mats[mat];
-                    const DevTexture T = S.tex[M.tex];
+                    const DevTexture T = M.tex_desc;
                     const double w = 1.0 - u - v;                                        // raytracer.rs:43
                     const double tex_x = A.uv[2] * u + A.uv[4] * v + A.uv[0] * w;        // raytracer.rs:45-47
                     const double tex_y = A.uv[3] * u + A.uv[5] * v + A.uv[1] * w;        // raytracer.rs:48-50
@@ -855,7 +855,7 @@ __device__ __forceinline__ uint32_t trace_colour(PROF_DECL const DevScene& S, co
                     // get_normal_at_intersection, raytracer.rs:114-162
                     V3 nn = (ld3(A.nrm + 3) * u + ld3(A.nrm + 6) * v) + ld3(A.nrm) * w;  // raytracer.rs:122-124
                     if (M.bump >= 0) {
-                        const DevTexture B = S.tex[M.bump];
+                        const DevTexture B = M.bump_desc;
                         const uint8_t* bp = B.rgb + 3ull * ((uint64_t)B.width * tyi + txi);  // raytracer.rs:127-128 (colour-texture indices, bump width)
                         V3 bv = mk((double)bp[0], (double)bp[1], (double)bp[2]);
                         bv = normalised(bv);
