@@ -120,6 +120,20 @@ def main() -> None:
     frame_no = [0]
     set_stream = torch.cuda.set_stream
     default_stream = torch.cuda.current_stream()
+    # plain fallback (no frames in flight: trace, gather, de-tile one after the other on the default stream), used with --pipeline-depth 0 or if the
+    # pipelined step raises in its first warm-up call on any rank
+    simple = [multi and args.pipeline_depth == 0]
+    if multi:
+        simple_tiles = rt.bind_render_tiles(mine[0], W, H, rank, world)
+        simple_detile = rt.bind_detile(gathered[0], fb, W, H, world) if rank == 0 else None
+
+    def simple_step(i: int | None) -> None:
+        if i is not None: ev[i][0].record()
+        simple_tiles()
+        if i is not None: ev[i][1].record()
+        dist.gather(mine[0], chunks[0], dst=0)
+        if rank == 0:
+            simple_detile()
 
     def step(i: int | None) -> None:
         if not multi:
@@ -127,6 +141,8 @@ def main() -> None:
             launch_frame()
             if i is not None: ev[i][1].record()
             return
+        if simple[0]:
+            simple_step(i); return
         b = frame_no[0] % DEPTH; frame_no[0] += 1
         ts = trace_streams[b]
         set_stream(ts)                                       # (torch.cuda.set_stream, not the context manager: the host side of a step is on the critical path at N = 8)
@@ -158,6 +174,22 @@ def main() -> None:
         torch.cuda.synchronize()
 
     torch.cuda.synchronize()                                 # buffers were zero-filled on the default stream; the slots run on their own
+    if multi and not simple[0]:
+        ok = 1
+        try:
+            step(None); fence()
+        except Exception as e:                               # noqa: BLE001 -- any failure of the pipelined choreography falls back to the plain step
+            print(f"[bench rank {rank}] pipelined step failed ({type(e).__name__}: {e}); falling back to the plain step", file=sys.stderr, flush=True)
+            ok = 0
+        if world > 1:
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            set_stream(default_stream)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if not ok:
+            simple[0] = True
+            for k in range(DEPTH): gather_work[k] = None; detile_pending[k] = False
+            set_stream(default_stream); torch.cuda.synchronize()
     for _ in range(args.warmup):
         step(None)
     fence()
@@ -272,7 +304,7 @@ def main() -> None:
                "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "reference scene assets/model2.obj (teapot+table+mirror, 6334 triangles), camera/lights of main.rs"
                if os.path.basename(args.scene) == "model2.obj" else "synthetic",
                "config": {"workload": f"{os.path.basename(args.scene)} {W}x{H}, 4 sub-samples/pixel, shadow rays + depth-5 mirror reflection, f64",
-                          "rays_primary_per_frame": rays_primary, "partition": "single launch" if world == 1 else f"8x8-pixel tiles round-robin over {world} GPUs + RCCL gather to GPU 0, {DEPTH} frames in flight (one stream per slot)",
+                          "rays_primary_per_frame": rays_primary, "partition": "single launch" if world == 1 else f"8x8-pixel tiles round-robin over {world} GPUs + " + "RCCL gather to GPU 0, " + ("one frame at a time" if simple[0] else f"{DEPTH} frames in flight (one stream per slot)"),
                           "octree_nodes": sd.info["n_nodes"], "triangles": sd.info["n_tris"]},
                "frame_ms": round(ms_per_step, 4), "kernel_ms": round(kernel_ms, 4), "host_enqueue_ms_per_step": round(host_enqueue_ms, 4), **({"rehearsal": "gloo on one GPU: NOT a benchmark result"} if rehearsal else {}),
                "frame_checksum": int(np.bitwise_xor.reduce(frame.ravel().astype(np.uint64) * np.arange(1, frame.size + 1, dtype=np.uint64)))}
