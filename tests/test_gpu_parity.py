@@ -414,3 +414,24 @@ def test_long_own_list_with_group_records(rrt, ob):
         rh, rt_, ru, rv, rtri = osc.intersect(o[i], d[i])
         assert bool(hit[i]) == rh and (not rh or (t[i], u[i], v[i], tri[i]) == (rt_, ru, rv, rtri)), i
     assert hit.mean() > 0.5
+
+
+def test_bench_multi_gpu_choreography_single_rank():
+    """bench.py's N > 1 step -- per-slot tile buffers and streams, asynchronous RCCL gather, de-tiling on a side stream, four frames in flight, and the
+    plain one-frame-at-a-time fallback -- run with ONE rank over RCCL on this GPU (RRT_BENCH_FORCE_DIST=1): the gathered, de-tiled frame must be the
+    single-launch frame (same checksum), and stdout must be exactly one JSON line."""
+    import json, subprocess, sys
+    root = os.path.dirname(ASSETS)
+    def run(env_extra, *flags):
+        env = dict(os.environ, MASTER_PORT=str(29600 + os.getpid() % 300), **env_extra)
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--steps", "6", "--warmup", "2", "--width", "320", "--height", "240", *flags],
+                           capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1, r.stdout
+        return json.loads(lines[0])
+    single = run({})
+    piped = run({"RRT_BENCH_FORCE_DIST": "1"})
+    plain = run({"RRT_BENCH_FORCE_DIST": "1"}, "--pipeline-depth", "0")
+    assert single["frame_checksum"] == piped["frame_checksum"] == plain["frame_checksum"]
+    assert single["n_gpus"] == 1 and single["unit"] == "Mrays/s"
