@@ -1,24 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X-native hot path (BASELINE.json: Mrays/s primary + frame ms, teapot @1920x1080).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--width 1920 --height 1080] [--scene assets/model2.obj] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--width 1920 --height 1080] [--scene assets/model2.obj | soup100000 | soup1000000]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    (a plain `python bench.py --gpus N` with no WORLD_SIZE in the environment starts those N ranks itself and relays rank 0's JSON line)
 
-A step = one full frame of the scene (Scene::draw_scene, engine.rs:186-255) with the scene already resident in HBM and the
-framebuffer left in HBM.  N = 1: one launch of the trace kernel writes the row-major framebuffer.  N > 1: the frame's 8x8-pixel
-tiles are dealt round-robin to the ranks (tile k -> rank k % N), each rank traces its tiles, one RCCL gather over xGMI
-collects the tile-major buffers on GPU 0, which de-tiles them to the row-major frame ("scaling": "strong" -- the frame is fixed).
-Rank 0 prints ONE JSON line.  The `roofline` object prices the trace kernel against the f64 VECTOR peak (this path is VALU-bound:
-no MFMA, almost no HBM traffic -- see DESIGN.md section 5) and carries the HBM figure the metric asks for as `hbm`.
-`cpu_baseline` is the oracle (restatement of the reference's rayon CPU path; the Rust reference cannot be built here) timed on
-the host cores -- a checker used as a reported baseline, never part of the product path.
+A step = one full frame of the scene (Scene::draw_scene, engine.rs:186-255) with the scene already resident in HBM and the framebuffer left in
+HBM.  N = 1: one launch of the trace kernel writes the row-major framebuffer.  N > 1: the frame's 8x8-pixel tiles are dealt round-robin to the
+ranks (tile k -> rank k % N), each rank traces its tiles, one RCCL gather over xGMI collects the tile-major buffers on GPU 0, which de-tiles them
+into the row-major frame ("scaling": "strong" -- the frame is fixed).  The documented configs[3] line is `--gpus 8 --width 3840 --height 2160`.
+Rank 0 prints ONE JSON line.
+
+`roofline` prices the trace kernel against the f64 VECTOR peak (the path is VALU-bound: no MFMA, almost no HBM traffic -- DESIGN.md section 4):
+`achieved` = f64 flop the hardware EXECUTED per launch (rocprofv3 SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 of the same command, committed under
+profiles/ and stamped with the sha256 of the kernel sources) / the kernel's launch duration measured live with HIP events; `frac` <= 1.  The
+reference algorithm's own flop count (oracle counters; the index skips most of that work) is reported beside it as `work_skipped_vs_reference`.
+`cpu_baseline` is the oracle (restatement of the reference's rayon CPU path; the Rust reference cannot be built here) timed on the host cores --
+a checker used as a reported baseline, never part of the product path.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,11 +35,42 @@ sys.path.insert(0, ROOT)
 
 FP64_VECTOR_PEAK_TFLOPS = 78.6     # MI355X f64 vector (non-matrix) peak: 256 CU x 128 FLOP/clk x 2.4 GHz (FMA = 2 FLOP); = 1/2 of the fp32 vector 157.3 TF in MI355X_MICROARCH.md
 HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+KERNEL_SOURCES = ("rust-ray-tracer_amd/csrc/render.hip", "rust-ray-tracer_amd/csrc/clusters.cpp", "rust-ray-tracer_amd/csrc/device_scene.hpp")
+
+
+def kernel_source_sha256() -> str:
+    """Identity of the code the PMC figures under profiles/ were measured on (tools/summarize_profiles.py stamps the same hash)."""
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def algorithmic_flops(c: dict) -> float:
     """full-path Moller-Trumbore 52 flop, slab test 24, shading ~250 per shaded hit."""
     return 52.0 * c["tri_tests"] + 24.0 * c["aabb_tests"] + 250.0 * c["hits_shaded"]
+
+
+def spawn_ranks(args, argv) -> int:
+    """`python bench.py --gpus N` outside a launcher: start the N ranks as fresh child processes (this process has not touched the GPU) and relay
+    rank 0's one JSON line."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + argv
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in p.stdout:
+        s = out.strip()
+        if s.startswith("{") and '"metric"' in s:
+            line = s
+        elif s:
+            print(s, file=sys.stderr, flush=True)
+    rc = p.wait()
+    if line:
+        print(line, flush=True)
+    return rc if rc else (0 if line else 1)
 
 
 def main() -> None:
@@ -42,10 +81,14 @@ def main() -> None:
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scene", default=os.path.join(ROOT, "assets", "model2.obj"))
-    ap.add_argument("--pipeline-depth", type=int, default=4, help="N > 1: frames in flight (gather + de-tiling of a frame overlap the tracing of the next); 1 = none")
+    ap.add_argument("--pipeline-depth", type=int, default=4, help="N > 1: frames in flight (gather + de-tiling of a frame overlap the tracing of the next); 0 = plain one-frame-at-a-time step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the bounded cpu_baseline sample")
+    ap.add_argument("--no-host-fb", action="store_true", help="skip the boundary-inclusive rrt_render timings (frame_ms_host_fb)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the bounded cpu_baseline leg (3 samples)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("RRT_BENCH_FORCE_DIST") != "1":
+        raise SystemExit(spawn_ranks(args, sys.argv[1:]))
 
     # stdout carries exactly ONE line, the JSON: RCCL prints a version banner and gloo its connection notes to fd 1 while the process group
     # comes up, so fd 1 points at stderr until the result is printed.
@@ -80,116 +123,151 @@ def main() -> None:
 
     rrt = importlib.import_module("rust-ray-tracer_amd")
     W, H = args.width, args.height
+    scene_name = os.path.basename(args.scene)
     if args.scene.startswith("soup"):   # soup100000 / soup1000000: the synthetic configs of BASELINE.json, generated on the spot (rank 0 writes the .obj)
         syn = importlib.import_module("rust-ray-tracer_amd.synthetic")
         n = int(args.scene[4:])
+        seed = syn.SEED_100K if n == 100000 else syn.SEED_1M if n == 1000000 else 0x5EED0003
         if rank == 0:
-            syn.ensure_soup(os.path.join(ROOT, "assets"), n, syn.SEED_100K if n == 100000 else syn.SEED_1M if n == 1000000 else 0x5EED0003)
+            syn.ensure_soup(os.path.join(ROOT, "assets"), n, seed)
         if world > 1:
             dist.barrier()
-        args.scene = syn.ensure_soup(os.path.join(ROOT, "assets"), n, syn.SEED_100K if n == 100000 else syn.SEED_1M if n == 1000000 else 0x5EED0003)
+        args.scene = syn.ensure_soup(os.path.join(ROOT, "assets"), n, seed)
+    t_setup = time.perf_counter()
     sd = rrt.parse_obj_file(args.scene)
     lights = rrt.default_lights()
     rt = rrt.RayTracer(sd, lights, rrt.DEFAULT_ORIGIN, device=local_rank)
+    setup_wall_ms = (time.perf_counter() - t_setup) * 1e3
+    setup = {k: round(v, 2) for k, v in rt.setup_times().items()}
+    setup["total_ms"] = round(sum(setup.values()), 2); setup["wall_ms_incl_binding"] = round(setup_wall_ms, 2)
 
     fb = torch.zeros((H, W), dtype=torch.int32, device="cuda")
-    DEPTH = max(1, args.pipeline_depth) if multi else 1
-    if multi:
-        # Frames in flight: frame i's gather (RCCL stream) and de-tiling (side stream on GPU 0) overlap the tracing of frame i+1, so each of the
-        # DEPTH slots has its own tile buffer, gather buffer and completion handles.  Every frame still goes trace -> gather -> de-tile in full.
-        tpr = rrt.tiles_per_rank(W, H, world)
-        mine = [torch.zeros(tpr * 64, dtype=torch.int32, device="cuda") for _ in range(DEPTH)]
-        gathered = [torch.zeros(world * tpr * 64, dtype=torch.int32, device="cuda") for _ in range(DEPTH)] if rank == 0 else [None] * DEPTH
-        # final gather to GPU 0 (BASELINE.json north_star): grouped point-to-point sends, every peer on its own xGMI link -- not a ring
-        chunks = [[g[i * tpr * 64:(i + 1) * tpr * 64] for i in range(world)] if rank == 0 else None for g in gathered]
-        side = torch.cuda.Stream() if (rank == 0 and not rehearsal) else None       # de-tiling stream of GPU 0
-        # each slot traces on its own stream: the next frame's waves fill the slots that the tail of the previous frame's launch leaves idle
-        # (at N = 8 a rank's launch is only ~4 waves per wave slot deep)
-        trace_streams = [torch.cuda.Stream() if not rehearsal else torch.cuda.current_stream() for _ in range(DEPTH)]
-        gather_work = [None] * DEPTH                                                # outstanding gather of each slot
-        detile_done = [torch.cuda.Event() for _ in range(DEPTH)]                    # slot's gather buffer has been de-tiled (GPU 0)
-        detile_pending = [False] * DEPTH
-
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    # pre-bound launchers: one ctypes call per launch in the timed loop
-    if not multi:
-        launch_frame = rt.bind_render(fb, W, H)
-    else:
-        launch_tiles = [rt.bind_render_tiles(m, W, H, rank, world, stream=ts.cuda_stream) for m, ts in zip(mine, trace_streams)]
-        launch_detile = [rt.bind_detile(g, fb, W, H, world, stream=(side.cuda_stream if side is not None else None)) for g in gathered] if rank == 0 else None
-    frame_no = [0]
     set_stream = torch.cuda.set_stream
     default_stream = torch.cuda.current_stream()
-    # plain fallback (no frames in flight: trace, gather, de-tile one after the other on the default stream), used with --pipeline-depth 0 or if the
-    # pipelined step raises in its first warm-up call on any rank
-    simple = [multi and args.pipeline_depth == 0]
-    if multi:
-        simple_tiles = rt.bind_render_tiles(mine[0], W, H, rank, world)
-        simple_detile = rt.bind_detile(gathered[0], fb, W, H, world) if rank == 0 else None
+    pipeline_fallback, pipeline_error = False, None
+    gather_ev = []
 
-    def simple_step(i: int | None) -> None:
-        if i is not None: ev[i][0].record()
-        simple_tiles()
-        if i is not None: ev[i][1].record()
-        dist.gather(mine[0], chunks[0], dst=0)
-        if rank == 0:
-            simple_detile()
+    if not multi:
+        DEPTH = 1
+        launch_frame = rt.bind_render(fb, W, H)
 
-    def step(i: int | None) -> None:
-        if not multi:
+        def step(i):
             if i is not None: ev[i][0].record()
             launch_frame()
             if i is not None: ev[i][1].record()
-            return
-        if simple[0]:
-            simple_step(i); return
-        b = frame_no[0] % DEPTH; frame_no[0] += 1
-        ts = trace_streams[b]
-        set_stream(ts)                                       # (torch.cuda.set_stream, not the context manager: the host side of a step is on the critical path at N = 8)
-        if gather_work[b] is not None:
-            gather_work[b].wait()                            # the slot's previous gather has read mine[b] (orders the slot's stream after it; the host does not block on RCCL)
-        if rank == 0 and detile_pending[b]:
-            ts.wait_event(detile_done[b])                    # ... and its gather buffer has been consumed before the next gather (issued after this point) overwrites it
-        if i is not None: ev[i][0].record(ts)
-        launch_tiles[b]()
-        if i is not None: ev[i][1].record(ts)
-        gather_work[b] = dist.gather(mine[b], chunks[b], dst=0, async_op=True)   # RCCL's stream waits for the slot's stream
-        if rank == 0:
-            if side is None:                                 # rehearsal (gloo): synchronous
-                gather_work[b].wait(); gather_work[b] = None
-                launch_detile[b]()
-            else:
-                set_stream(side)
-                gather_work[b].wait()                        # side stream waits for the gather; the tracing streams go on with the next frames
-                launch_detile[b]()
-                detile_done[b].record(side); detile_pending[b] = True
 
-    def fence() -> None:
-        if multi:
+        def fence():
+            torch.cuda.synchronize()
+    else:
+        # ---- N > 1.  Everything that can fail locally (buffers, streams, bound launchers, the filter tuning inside the first launch) is set up
+        # and exercised BEFORE any collective of the pipelined step is issued; the ranks then agree (one all_reduce) on pipelined vs plain.  A
+        # failure after that point is not recoverable without risking mismatched collectives: the rank tears the process group down and exits non-zero.
+        tpr = rrt.tiles_per_rank(W, H, world)
+        want_pipeline = args.pipeline_depth > 0
+        DEPTH = max(1, args.pipeline_depth)
+        ok = 1
+        try:
+            # Frames in flight: frame i's gather (RCCL stream) and de-tiling (side stream on GPU 0) overlap the tracing of frame i+1, so each of
+            # the DEPTH slots has its own tile buffer, gather buffer and completion handles.  Every frame still goes trace -> gather -> de-tile in full.
+            mine = [torch.zeros(tpr * 64, dtype=torch.int32, device="cuda") for _ in range(DEPTH)]
+            gathered = [torch.zeros(world * tpr * 64, dtype=torch.int32, device="cuda") for _ in range(DEPTH)] if rank == 0 else [None] * DEPTH
+            # final gather to GPU 0 (BASELINE.json north_star): grouped point-to-point sends, every peer on its own xGMI link -- not a ring
+            chunks = [[g[i * tpr * 64:(i + 1) * tpr * 64] for i in range(world)] if rank == 0 else None for g in gathered]
+            side = torch.cuda.Stream() if (rank == 0 and not rehearsal) else None       # de-tiling stream of GPU 0
+            # each slot traces on its own stream: the next frame's waves fill the slots that the tail of the previous frame's launch leaves idle
+            trace_streams = [torch.cuda.Stream() if not rehearsal else torch.cuda.current_stream() for _ in range(DEPTH)]
+            launch_tiles = [rt.bind_render_tiles(m, W, H, rank, world, stream=ts.cuda_stream) for m, ts in zip(mine, trace_streams)]
+            launch_detile = [rt.bind_detile(g, fb, W, H, world, stream=(side.cuda_stream if side is not None else None)) for g in gathered] if rank == 0 else None
+            simple_tiles = rt.bind_render_tiles(mine[0], W, H, rank, world)
+            simple_detile = rt.bind_detile(gathered[0], fb, W, H, world) if rank == 0 else None
+            for lt in launch_tiles: lt()                                                 # local launches only: tunes the filter variant, proves the kernels run
+            simple_tiles()
+            if rank == 0: launch_detile[0](); simple_detile()
+            torch.cuda.synchronize()
+        except Exception as e:                                                           # noqa: BLE001
+            ok = 0; pipeline_error = f"rank {rank}: {type(e).__name__}: {e}"
+            print(f"[bench rank {rank}] local set-up of the N > 1 step failed: {pipeline_error}", file=sys.stderr, flush=True)
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            dist.destroy_process_group()
+            raise SystemExit(f"bench.py: the N > 1 step could not be set up on every rank ({pipeline_error or 'another rank failed'})")
+        gather_work = [None] * DEPTH                                                # outstanding gather of each slot
+        detile_done = [torch.cuda.Event() for _ in range(DEPTH)]                    # slot's gather buffer has been de-tiled (GPU 0)
+        detile_pending = [False] * DEPTH
+        frame_no = [0]
+        simple = [not want_pipeline]
+        gather_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)] if rank == 0 else []
+
+        def simple_step(i):
+            if i is not None: ev[i][0].record()
+            simple_tiles()
+            if i is not None: ev[i][1].record()
+            dist.gather(mine[0], chunks[0], dst=0)
+            if rank == 0:
+                simple_detile()
+                if i is not None: gather_ev[i][0].record(); gather_ev[i][1].record()   # (plain step: gather and de-tile are in line; no separate figure)
+
+        def pipelined_step(i):
+            b = frame_no[0] % DEPTH; frame_no[0] += 1
+            ts = trace_streams[b]
+            set_stream(ts)                                       # (torch.cuda.set_stream, not the context manager: the host side of a step is on the critical path at N = 8)
+            if gather_work[b] is not None:
+                gather_work[b].wait()                            # the slot's previous gather has read mine[b] (orders the slot's stream after it; the host does not block on RCCL)
+            if rank == 0 and detile_pending[b]:
+                ts.wait_event(detile_done[b])                    # ... and its gather buffer has been consumed before the next gather (issued after this point) overwrites it
+            if i is not None: ev[i][0].record(ts)
+            launch_tiles[b]()
+            if i is not None: ev[i][1].record(ts)
+            gather_work[b] = dist.gather(mine[b], chunks[b], dst=0, async_op=True)   # RCCL's stream waits for the slot's stream
+            if rank == 0:
+                if side is None:                                 # rehearsal (gloo): synchronous
+                    gather_work[b].wait(); gather_work[b] = None
+                    launch_detile[b]()
+                else:
+                    set_stream(side)
+                    if i is not None: gather_ev[i][0].record(side)
+                    gather_work[b].wait()                        # side stream waits for the gather; the tracing streams go on with the next frames
+                    launch_detile[b]()
+                    if i is not None: gather_ev[i][1].record(side)
+                    detile_done[b].record(side); detile_pending[b] = True
+
+        def step(i):
+            try:
+                simple_step(i) if simple[0] else pipelined_step(i)
+            except Exception as e:                               # noqa: BLE001 -- collectives are in flight: no safe fallback from here
+                print(f"[bench rank {rank}] step failed after collectives were issued ({type(e).__name__}: {e}); aborting", file=sys.stderr, flush=True)
+                try:
+                    dist.destroy_process_group()
+                finally:
+                    os._exit(3)
+
+        def fence():
             set_stream(default_stream)
             for w in gather_work:
                 if w is not None: w.wait()
             torch.cuda.synchronize()
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
-    torch.cuda.synchronize()                                 # buffers were zero-filled on the default stream; the slots run on their own
-    if multi and not simple[0]:
-        ok = 1
-        try:
-            step(None); fence()
-        except Exception as e:                               # noqa: BLE001 -- any failure of the pipelined choreography falls back to the plain step
-            print(f"[bench rank {rank}] pipelined step failed ({type(e).__name__}: {e}); falling back to the plain step", file=sys.stderr, flush=True)
-            ok = 0
-        if world > 1:
+        # one full pipelined step per slot, then agree again: a rank whose pipelined choreography misbehaves WITHOUT raising (wrong frame) cannot be
+        # detected here, but a rank that sees an error state on its streams can still vote for the plain step before the timed region
+        if not simple[0]:
+            for _ in range(DEPTH): step(None)
+            fence()
+            ok = 1
+            try:
+                torch.cuda.synchronize()
+            except Exception as e:                               # noqa: BLE001
+                ok = 0; pipeline_error = f"rank {rank}: {type(e).__name__}: {e}"
             flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-            set_stream(default_stream)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ok = int(flag.item())
-        if not ok:
-            simple[0] = True
-            for k in range(DEPTH): gather_work[k] = None; detile_pending[k] = False
-            set_stream(default_stream); torch.cuda.synchronize()
+            if int(flag.item()) == 0:
+                pipeline_fallback = True; simple[0] = True
+                for k in range(DEPTH): gather_work[k] = None; detile_pending[k] = False
+
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step(None)
     fence()
@@ -199,27 +277,52 @@ def main() -> None:
     host_enqueue_ms = (time.perf_counter() - t0) / args.steps * 1e3   # host time to issue one step (launch + gather + de-tile calls), before any waiting
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))   # trace kernel only, HIP events on its launch stream
-    if world > 1:
-        kmax = torch.tensor([kernel_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
-        kernel_ms = float(kmax.item())
+    kernel_ms_min = kernel_ms_max = kernel_ms
+    gather_ms = None
+    if multi:
+        t = torch.tensor([elapsed, kernel_ms, -kernel_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms_max, kernel_ms_min = float(t[0]), float(t[1]), -float(t[2])
+        kernel_ms = kernel_ms_max
+        if rank == 0 and gather_ev and not simple[0] and not rehearsal:
+            gather_ms = float(np.mean([a.elapsed_time(b) for a, b in gather_ev]))   # side stream: wait for the RCCL gather of the slot + de-tile
 
     if rank == 0:
         traced_rows = 2 * (H // 2) - 1                       # y = -H/2 is computed by the reference but its pixels are rejected by put_pixel; not traced here
         rays_primary = 4 * (2 * (W // 2)) * traced_rows
         ms_per_step = elapsed / args.steps * 1e3
         frame = fb.cpu().numpy().view(np.uint32)
+        workload_key = f"{'soup' + str(sd.info['n_tris']) if scene_name.startswith('soup') else scene_name}@{W}x{H}"
 
-        # --- work counters for the algorithmic flop count (oracle counters; committed for the headline config, else scaled from the CPU sample)
-        key = f"{os.path.basename(args.scene)}@{W}x{H}"
+        # --- boundary-inclusive frame: rrt_render into a HOST framebuffer, as the Rust host's Canvas.buffer receives it (engine.rs:127,246-250)
+        host_fb = None
+        if world == 1 and not multi and not args.no_host_fb:
+            n_host = max(5, min(50, args.steps))
+            buf = np.empty((H, W), np.uint32)
+            L = rrt.lib(); import ctypes as C
+            ptr = buf.ctypes.data_as(C.POINTER(C.c_uint32))
+            def timed():
+                for _ in range(3): L.rrt_render(rt._h, W, H, ptr)
+                tt = time.perf_counter()
+                for _ in range(n_host): L.rrt_render(rt._h, W, H, ptr)
+                return (time.perf_counter() - tt) / n_host * 1e3
+            pageable = timed()
+            same = bool(np.array_equal(buf, frame))
+            L.rrt_host_buffer_register(C.c_void_p(buf.ctypes.data), buf.nbytes)
+            try:
+                registered = timed()
+                same = same and bool(np.array_equal(buf, frame))
+            finally:
+                L.rrt_host_buffer_unregister(C.c_void_p(buf.ctypes.data))
+            host_fb = {"frame_ms_host_fb": round(registered, 4), "frame_ms_host_fb_pageable": round(pageable, 4), "frames": n_host, "identical_to_device_frame": same,
+                       "note": "wall time of the blocking rrt_render(rt, w, h, host_fb): kernel + device->host copy; `frame_ms_host_fb` with the caller's buffer page-locked "
+                               "(rrt_host_buffer_register: one DMA), `..._pageable` through the library's pinned staging + pipelined host copy"}
+
+        # --- work counters for the reference algorithm's flop count (oracle counters; committed for the headline config, else scaled from the CPU sample)
         counters, counters_src = None, None
         try:
-            counters = json.load(open(os.path.join(ROOT, "bench_data", "work_counters.json")))["counters"].get(key)
+            counters = json.load(open(os.path.join(ROOT, "bench_data", "work_counters.json")))["counters"].get(workload_key)
             counters_src = "bench_data/work_counters.json (oracle, exact for this frame)" if counters else None
         except OSError:
             pass
@@ -235,19 +338,23 @@ def main() -> None:
             except AttributeError:
                 pass
             tp = time.perf_counter(); osc.render(W // 8, H // 8, n_threads=cores); probe = time.perf_counter() - tp
-            div = 1
+            per_sample = args.cpu_seconds / 3.0
+            div = 8
             for cand in (1, 2, 3, 4, 6, 8):                   # largest sample (1/div of each dimension) expected to fit the time budget
-                if probe * 64.0 / (cand * cand) <= args.cpu_seconds:
+                if probe * 64.0 / (cand * cand) <= per_sample:
                     div = cand; break
-                div = cand
             sw, sh = W // div, H // div
-            tp = time.perf_counter(); ref, cnt = osc.render(sw, sh, n_threads=cores); cpu_s = time.perf_counter() - tp
+            secs = []
+            for _ in range(3):
+                tp = time.perf_counter(); ref, cnt = osc.render(sw, sh, n_threads=cores); secs.append(time.perf_counter() - tp)
+            cpu_s = float(np.median(secs))
             cpu_rays = cnt["rays_primary"]
             cpu = {"value": round(cpu_rays / cpu_s / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-                   "sample": f"oracle (f64 C restatement of the reference rayon path, -O3 -ffp-contract=off) rendering {os.path.basename(args.scene)} at {sw}x{sh} "
-                             f"({cpu_rays} primary rays incl. the discarded row) in {cpu_s:.2f} s on {cores} threads; parallel over the rows of one 50-row chunk at a time "
-                             f"with a barrier per chunk, as the reference's rayon loop (engine.rs:196-203), so at most 50 threads are busy at once",
-                   "frame_ms_at_sample": round(cpu_s * 1e3, 1)}
+                   "sample": f"oracle (f64 C restatement of the reference rayon path, -O3 -ffp-contract=off) rendering {scene_name} at {sw}x{sh} "
+                             f"({cpu_rays} primary rays incl. the discarded row): median of 3 samples ({', '.join(f'{s:.2f}' for s in secs)} s; the /8-size probe before them is the warm-up) "
+                             f"on {cores} threads; parallel over the rows of one 50-row chunk at a time with a barrier per chunk, as the reference's rayon loop "
+                             f"(engine.rs:196-203), so at most 50 threads are busy at once",
+                   "frame_ms_at_sample": round(cpu_s * 1e3, 1), "samples": 3}
             if div == 1:
                 d = np.abs(np.stack([(frame >> s) & 255 for s in (16, 8, 0)], -1).astype(np.int64) - np.stack([(ref >> s) & 255 for s in (16, 8, 0)], -1).astype(np.int64))
                 cpu["gpu_vs_cpu_max_channel_diff"] = int(d.max())
@@ -256,60 +363,79 @@ def main() -> None:
                 counters = {k: v * scale for k, v in cnt.items()}
                 counters_src = f"oracle counters of the {sw}x{sh} CPU sample scaled by ray count"
 
-        roofline = None
+        # --- roofline: executed f64 flop (rocprofv3 PMC of this workload, committed under profiles/, valid only for the kernel sources it was measured on)
+        per_rank = 1.0 / world
+        prof, prof_reason = None, None
+        try:
+            allp = json.load(open(os.path.join(ROOT, "profiles", "current_summary.json")))
+            if allp.get("source_sha256") != kernel_source_sha256():
+                prof_reason = "profiles/current_summary.json was measured on different kernel sources (source_sha256 mismatch): re-run tools/collect_profiles.sh"
+            elif world != 1:
+                prof_reason = "PMC profile is of the single-GPU launch"
+            else:
+                prof = allp.get("workloads", {}).get(workload_key)
+                if prof is None:
+                    prof_reason = f"no PMC profile of {workload_key} under profiles/"
+        except (OSError, ValueError) as e:
+            prof_reason = f"profiles/current_summary.json unreadable: {e}"
+        executed, traffic, achieved, frac, valu_issue = None, None, None, None, None
+        if prof:
+            pm = prof["pmc_avg_per_launch"]
+            ex_flop = prof.get("executed_f64_flop_per_launch_upper_bound")
+            prof_ms = float(prof["kernel_stats"]["AverageNs"]) * 1e-6
+            achieved = ex_flop / (kernel_ms * 1e-3) / 1e12 if ex_flop else None
+            frac = achieved / FP64_VECTOR_PEAK_TFLOPS if achieved else None
+            # SQ_ACTIVE_INST_VALU counts quad-cycles summed over waves; 1024 SIMDs; clock taken as the 2.4 GHz peak (lower bound on busy)
+            valu_issue = pm["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024 * 2.4e9 * prof_ms * 1e-3) if "SQ_ACTIVE_INST_VALU" in pm else None
+            executed = {"source": f"profiles/current_summary.json [{workload_key}] (rocprofv3 --pmc, same command, one pass per counter group; kernel sources sha256 {allp['source_sha256'][:12]})",
+                        "profiled_kernel_ms": round(prof_ms, 4), "rocprof_vs_live_kernel_ms": round(prof_ms / kernel_ms, 3), "valu_insts_per_launch": pm.get("SQ_INSTS_VALU"),
+                        "f64_flop_per_launch": ex_flop,
+                        "f64_valu_inst_share": round((pm.get("SQ_INSTS_VALU_ADD_F64", 0) + pm.get("SQ_INSTS_VALU_MUL_F64", 0) + pm.get("SQ_INSTS_VALU_FMA_F64", 0) + pm.get("SQ_INSTS_VALU_TRANS_F64", 0)) / pm["SQ_INSTS_VALU"], 3) if pm.get("SQ_INSTS_VALU") else None}
+            hb = prof.get("hbm_bytes_per_launch")
+            if hb:
+                traffic = hb["fetch_x2_gfx950_correction"] + hb["write"]   # MI355X_MICROARCH.md: FETCH_SIZE reads half the bytes of a wide stream on gfx950
+        hbm_bytes = rt.last_stats()["scene_bytes"] + 4.0 * W * H * per_rank
+        roofline = {"bound": "valu", "kernel": "render_kernel", "achieved": round(achieved, 3) if achieved else None, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(frac, 4) if frac else None, "traffic": traffic, "valu_issue_frac": round(valu_issue, 3) if valu_issue else None,
+                    "kernel_ms": round(kernel_ms, 4),
+                    "note": "achieved = f64 flop EXECUTED per launch (rocprofv3 SQ_INSTS_VALU_{ADD,MUL,FMA x2,TRANS}_F64 x 64 lanes) / live kernel time; peak = f64 vector peak with FMA, "
+                            "which the reference's unfused arithmetic (-ffp-contract=off, required for parity) can reach at most half of",
+                    "executed": executed, "executed_unavailable_reason": prof_reason,
+                    "hbm": {"algorithmic_bytes_per_launch": hbm_bytes, "achieved": round(hbm_bytes / (kernel_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBPS,
+                            "unit": "GB/s", "frac": round(hbm_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6),
+                            "measured_bytes_per_launch": traffic, "measured_over_algorithmic": round(traffic / hbm_bytes, 2) if traffic else None,
+                            "note": "algorithmic = scene (uploaded once, L2/MALL resident) + framebuffer; the path is not HBM-bound"}}
         if counters is not None:
-            # ALGORITHMIC work = what the reference's algorithm does for this frame (oracle counters): every triangle of every visited node's list
-            # is tested, every child box slab-tested.  The kernel reaches the same pixels while skipping most of that work (result-preserving
-            # cluster/subtree index), so algorithmic flop/s can exceed the machine peak; `executed` holds what the hardware really ran (rocprofv3
-            # PMC of the same command, profiles/current_summary.json) and is the utilisation figure.
+            # what the REFERENCE's algorithm does for this frame (every triangle of every visited node's list tested, every child box slab-tested);
+            # the kernel reaches the same pixels while skipping most of it (result-preserving index), so this is a work ratio, not a utilisation
             flops = algorithmic_flops(counters)
-            rays_all = counters["rays_primary"] + counters["rays_shadow"] + counters["rays_reflect"]
-            per_rank = 1.0 / world
-            ach = flops * per_rank / (kernel_ms * 1e-3) / 1e12
-            hbm_bytes = rt.last_stats()["scene_bytes"] + 4.0 * W * H * per_rank
-            prof = None
-            try:
-                prof = json.load(open(os.path.join(ROOT, "profiles", "current_summary.json")))
-            except OSError:
-                pass
-            executed, traffic = None, None
-            if prof and world == 1 and (W, H) == (1920, 1080) and os.path.basename(args.scene) == "model2.obj":
-                pm = prof["pmc_avg_per_launch"]
-                ex_flop = prof.get("executed_f64_flop_per_launch_upper_bound")
-                prof_ms = float(prof["kernel_stats"]["AverageNs"]) * 1e-6
-                executed = {"source": "profiles/current_summary.json (rocprofv3 --pmc, same command, one pass per counter group)",
-                            "profiled_kernel_ms": round(prof_ms, 4), "valu_insts_per_launch": pm.get("SQ_INSTS_VALU"),
-                            "f64_flop_per_launch_upper_bound": ex_flop,
-                            "f64_tflops": round(ex_flop / (prof_ms * 1e-3) / 1e12, 3) if ex_flop else None,
-                            "f64_frac_of_peak": round(ex_flop / (prof_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS, 4) if ex_flop else None,
-                            # SQ_ACTIVE_INST_VALU counts quad-cycles summed over waves; 1024 SIMDs; clock taken as the 2.4 GHz peak (lower bound on busy)
-                            "valu_busy_frac_at_2p4GHz": round(pm["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024 * 2.4e9 * prof_ms * 1e-3), 3) if "SQ_ACTIVE_INST_VALU" in pm else None,
-                            "algorithmic_over_executed_flop": round(flops / ex_flop, 1) if ex_flop else None}
-                hb = prof.get("hbm_bytes_per_launch")
-                if hb:
-                    traffic = hb["fetch_x2_gfx950_correction"] + hb["write"]   # MI355X_MICROARCH.md: FETCH_SIZE reads half the bytes of a wide stream on gfx950
-            roofline = {"bound": "valu", "kernel": "render_kernel", "achieved": round(ach, 3), "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / FP64_VECTOR_PEAK_TFLOPS, 4), "traffic": traffic,
-                        "note": "achieved = reference-algorithm flop / kernel time; > peak means the index skipped that work, see `executed` for hardware utilisation",
-                        "kernel_ms": round(kernel_ms, 4), "algorithmic_flops_per_launch": flops * per_rank,
-                        "flop_model": "52*tri_tests + 24*aabb_tests + 250*hits_shaded (SURVEY.md 8d), counts from the oracle",
-                        "counters": {k: (int(v) if float(v).is_integer() else v) for k, v in counters.items() if k != "seconds_8_threads_container"},
-                        "counters_source": counters_src, "rays_all_kinds": int(rays_all), "executed": executed,
-                        "hbm": {"algorithmic_bytes_per_launch": hbm_bytes, "achieved": round(hbm_bytes / (kernel_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBPS,
-                                "unit": "GB/s", "frac": round(hbm_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6),
-                                "note": "scene (uploaded once, L2/MALL resident) + framebuffer; the path is not HBM-bound"}}
+            alg_tflops = flops * per_rank / (kernel_ms * 1e-3) / 1e12
+            roofline["reference_algorithm"] = {"flops_per_launch": flops * per_rank, "tflops_equivalent": round(alg_tflops, 3),
+                                               "work_skipped_vs_reference": round(flops / prof["executed_f64_flop_per_launch_upper_bound"], 1) if prof and prof.get("executed_f64_flop_per_launch_upper_bound") else None,
+                                               "equivalent_over_peak": round(alg_tflops / FP64_VECTOR_PEAK_TFLOPS, 3),
+                                               "flop_model": "52*tri_tests + 24*aabb_tests + 250*hits_shaded (SURVEY.md 8d), counts from the oracle",
+                                               "counters": {k: (int(v) if float(v).is_integer() else v) for k, v in counters.items() if k != "seconds_8_threads_container"},
+                                               "counters_source": counters_src,
+                                               "rays_all_kinds": int(counters["rays_primary"] + counters["rays_shadow"] + counters["rays_reflect"])}
 
-        out = {"metric": "Mrays/s (primary) at 1920x1080, Utah teapot (model2.obj)" if (W, H) == (1920, 1080) else f"Mrays/s (primary) at {W}x{H}",
+        teapot = scene_name == "model2.obj"
+        out = {"metric": "Mrays/s (primary) at 1920x1080, Utah teapot (model2.obj)" if (teapot and (W, H) == (1920, 1080)) else f"Mrays/s (primary) at {W}x{H}, {scene_name}",
                "value": round(rays_primary / (elapsed / args.steps) / 1e6, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "reference scene assets/model2.obj (teapot+table+mirror, 6334 triangles), camera/lights of main.rs"
-               if os.path.basename(args.scene) == "model2.obj" else "synthetic",
-               "config": {"workload": f"{os.path.basename(args.scene)} {W}x{H}, 4 sub-samples/pixel, shadow rays + depth-5 mirror reflection, f64",
-                          "rays_primary_per_frame": rays_primary, "partition": "single launch" if world == 1 else f"8x8-pixel tiles round-robin over {world} GPUs + " + "RCCL gather to GPU 0, " + ("one frame at a time" if simple[0] else f"{DEPTH} frames in flight (one stream per slot)"),
-                          "octree_nodes": sd.info["n_nodes"], "triangles": sd.info["n_tris"]},
-               "frame_ms": round(ms_per_step, 4), "kernel_ms": round(kernel_ms, 4), "host_enqueue_ms_per_step": round(host_enqueue_ms, 4), **({"rehearsal": "gloo on one GPU: NOT a benchmark result"} if rehearsal else {}),
+               "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+               "data": "reference scene assets/model2.obj (teapot+table+mirror, 6334 triangles), camera/lights of main.rs" if teapot else f"synthetic ({scene_name}: SURVEY.md 8d soup recipe)" if scene_name.startswith("soup") else f"reference scene {scene_name}",
+               "config": {"workload": f"{scene_name} {W}x{H}, 4 sub-samples/pixel, shadow rays + depth-5 mirror reflection, f64",
+                          "rays_primary_per_frame": rays_primary,
+                          "partition": "single launch" if not multi else f"8x8-pixel tiles round-robin over {world} GPUs + RCCL gather to GPU 0, " + ("one frame at a time" if simple[0] else f"{DEPTH} frames in flight (one stream per slot)"),
+                          "octree_nodes": sd.info["n_nodes"], "triangles": sd.info["n_tris"], "filter_variant": "bundle" if rt.last_stats()["filter_variant"] else "lane"},
+               "frame_ms": round(ms_per_step, 4), "kernel_ms": round(kernel_ms, 4), "host_enqueue_ms_per_step": round(host_enqueue_ms, 4), "setup_ms": setup,
+               **({"rehearsal": "gloo on one GPU: NOT a benchmark result"} if rehearsal else {}),
                "frame_checksum": int(np.bitwise_xor.reduce(frame.ravel().astype(np.uint64) * np.arange(1, frame.size + 1, dtype=np.uint64)))}
-        if roofline is not None:
-            out["roofline"] = roofline
+        if multi:
+            out.update({"pipeline_fallback": pipeline_fallback, "pipeline_error": pipeline_error, "kernel_ms_per_rank_min": round(kernel_ms_min, 4),
+                        "kernel_ms_per_rank_max": round(kernel_ms_max, 4), "gather_ms": round(gather_ms, 4) if gather_ms is not None else None})
+        if host_fb is not None:
+            out.update({"frame_ms_host_fb": host_fb["frame_ms_host_fb"], "host_fb": host_fb})
+        out["roofline"] = roofline
         if cpu is not None:
             out["cpu_baseline"] = cpu
         sys.stdout.flush()

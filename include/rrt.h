@@ -16,6 +16,7 @@
  */
 #ifndef RRT_H
 #define RRT_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -127,6 +128,12 @@ void rrt_raytracer_destroy(rrt_raytracer *rt);
  * odd sizes row 1 / the last column) are 0 as in Canvas::new (engine.rs:135).  Blocking. */
 int rrt_render(rrt_raytracer *rt, uint32_t width, uint32_t height, uint32_t *out_fb);
 
+/* Optional: page-lock a caller-owned framebuffer (the Rust host's Canvas.buffer: Vec<u32>, engine.rs:127) so that rrt_render copies the
+ * frame into it with one asynchronous DMA.  Without it rrt_render stages through pinned memory of its own plus one host copy
+ * (pipelined in row chunks).  Unregister before the buffer is freed or reallocated. */
+int rrt_host_buffer_register(void *ptr, size_t bytes);
+int rrt_host_buffer_unregister(void *ptr);
+
 /* Same, framebuffer in device memory of rt's device; enqueued on `stream` (hipStream_t, NULL = default), not synchronised. */
 int rrt_render_device(rrt_raytracer *rt, uint32_t width, uint32_t height, void *d_fb, void *stream);
 
@@ -158,6 +165,11 @@ int rrt_intersect_rays(rrt_raytracer *rt, uint32_t n, const double *origins, con
                        uint8_t *hit, double *t, double *u, double *v, uint32_t *tri);
 
 int rrt_last_stats(const rrt_raytracer *rt, rrt_stats *out);
+/* Wall time of the set-up stages that run once per scene (the reference does all of them inside parse_obj_file_lines, utils.rs:139-213,
+ * before its one frame): model side = file read, .obj/.mtl parse, texture decode, octree build (octree.rs:41-241); raytracer side =
+ * own-list index build (clusters.cpp) and upload to HBM.  Either handle may be NULL (its fields stay 0). */
+typedef struct { double read_ms, parse_ms, texture_ms, octree_ms, index_ms, upload_ms; } rrt_setup_times;
+int rrt_get_setup_times(const rrt_model *m, const rrt_raytracer *rt, rrt_setup_times *out);
 int rrt_device_count(int *count);
 const char *rrt_strerror(int status);
 const char *rrt_last_error_detail(void);   /* thread-local text of the last failure */

@@ -67,6 +67,10 @@ class CStats(C.Structure):
                 ("filter_variant", C.c_uint32), ("_pad", C.c_uint32)]
 
 
+class CSetupTimes(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("read_ms", "parse_ms", "texture_ms", "octree_ms", "index_ms", "upload_ms")]
+
+
 # every symbol include/rrt.h declares: (restype, argtypes)
 _P = C.c_void_p
 _dp, _u32p, _u8p = C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)
@@ -84,6 +88,8 @@ SYMBOLS = {
     "rrt_raytracer_create": (C.c_int, [_P, C.POINTER(CLight), C.c_uint32, Vec3, C.POINTER(COptions), C.c_int, C.POINTER(_P)]),
     "rrt_raytracer_destroy": (None, [_P]),
     "rrt_render": (C.c_int, [_P, C.c_uint32, C.c_uint32, _u32p]),
+    "rrt_host_buffer_register": (C.c_int, [_P, C.c_size_t]),
+    "rrt_host_buffer_unregister": (C.c_int, [_P]),
     "rrt_render_device": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P]),
     "rrt_tiles_per_rank": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32]),
     "rrt_render_tiles_device": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P]),
@@ -92,6 +98,7 @@ SYMBOLS = {
     "rrt_get_ray_colours": (C.c_int, [_P, C.c_uint32, _dp, _dp, _u32p]),
     "rrt_intersect_rays": (C.c_int, [_P, C.c_uint32, _dp, _dp, _dp, _u8p, _dp, _dp, _dp, _u32p]),
     "rrt_last_stats": (C.c_int, [_P, C.POINTER(CStats)]),
+    "rrt_get_setup_times": (C.c_int, [_P, _P, C.POINTER(CSetupTimes)]),
     "rrt_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "rrt_strerror": (C.c_char_p, [C.c_int]),
     "rrt_last_error_detail": (C.c_char_p, []),
@@ -363,6 +370,24 @@ class RayTracer:
             if rc != OK:
                 _check(rc, "rrt_detile_device")
         return launch
+
+    def setup_times(self) -> dict:
+        """Wall ms of the once-per-scene stages: read, parse, texture decode, octree (model) + index, upload (this raytracer)."""
+        t = CSetupTimes()
+        _check(lib().rrt_get_setup_times(self.scene_data._h, self._h, C.byref(t)), "rrt_get_setup_times")
+        return {n: getattr(t, n) for n, _ in CSetupTimes._fields_}
+
+    def render_registered(self, width: int, height: int, fb: Optional[np.ndarray] = None) -> np.ndarray:
+        """rrt_render into a page-locked framebuffer (rrt_host_buffer_register): the frame arrives by one asynchronous DMA."""
+        if fb is None:
+            fb = np.empty((height, width), np.uint32)
+        p = _P(fb.ctypes.data)
+        _check(lib().rrt_host_buffer_register(p, fb.nbytes), "rrt_host_buffer_register")
+        try:
+            _check(lib().rrt_render(self._h, width, height, fb.ctypes.data_as(_u32p)), "rrt_render")
+        finally:
+            _check(lib().rrt_host_buffer_unregister(p), "rrt_host_buffer_unregister")
+        return fb
 
     def last_stats(self) -> dict:
         s = CStats()

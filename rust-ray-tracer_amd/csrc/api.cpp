@@ -2,6 +2,8 @@
 // No CPU rendering path exists in this library; every compute entry point launches the HIP kernels of render.hip.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -26,6 +28,12 @@ struct rrt_raytracer {
     bool variant_forced = false;
     void* host_fb = nullptr;         // device framebuffer kept between rrt_render calls (host-buffer entry point)
     size_t host_fb_bytes = 0;
+    double index_ms = 0, upload_ms = 0;  // set-up stages of rrt_raytracer_create
+    hipStream_t own_stream = nullptr;   // rrt_render's stream (non-blocking: independent of the legacy default stream)
+    void* staging = nullptr;         // pinned host staging for callers whose framebuffer is pageable memory
+    size_t staging_bytes = 0;
+    static constexpr int kCopyChunks = 8;
+    hipEvent_t chunk_ev[kCopyChunks] = {};
     uint32_t tuned_w = 0, tuned_h = 0, tuned_world = 0;
 };
 
@@ -230,7 +238,9 @@ int rrt_model_from_arrays(uint32_t n_tris, const double* pos, const double* uv, 
             t.n1 = rd(nrm + 9 * (size_t)i); t.n2 = rd(nrm + 9 * (size_t)i + 3); t.n3 = rd(nrm + 9 * (size_t)i + 6);
             t.mat = mat[i];
         }
+        const auto t0 = std::chrono::steady_clock::now();
         build_octree(M.triangles, M.root, M.tree);
+        M.octree_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         validate_model(M);
         *out = m.release();
         return RRT_OK;
@@ -334,6 +344,8 @@ int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n
         const Model& M = m->m; const FlatOctree& T = M.tree;
         const size_t n_nodes = T.box.size(), n_slots = T.own_idx.size();   // n_slots: every triangle in the tree appears in exactly one own list
 
+        using clk = std::chrono::steady_clock;
+        const auto t_index0 = clk::now();
         ClusterSet CS;
         build_clusters(M, !(o.flags & RRT_FLAG_NO_CULL), CS);
         const size_t n_slots_c = CS.slot_tri.size();
@@ -369,6 +381,7 @@ int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n
             a.nrm[6] = t.n3.x; a.nrm[7] = t.n3.y; a.nrm[8] = t.n3.z;
             a.mat = t.mat; a.orig = CS.slot_tri[s];
         }
+        const auto t_index1 = clk::now();
         std::vector<DevTexture> texs(M.textures.size());
         for (size_t i = 0; i < texs.size(); i++) {
             texs[i].rgb = upload(rt.get(), M.textures[i].rgb.data(), M.textures[i].rgb.size());
@@ -400,7 +413,7 @@ int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n
         S.mats = upload(rt.get(), mats.data(), mats.size());
         S.tex = upload(rt.get(), texs.data(), texs.size());
         S.n_nodes = (uint32_t)n_nodes; S.n_slots = (uint32_t)n_slots; S.n_mats = (uint32_t)mats.size(); S.n_tex = (uint32_t)texs.size();
-        S.n_lights = n_lights; S.max_reflection_depth = o.max_reflection_depth; S.stack_levels = T.max_depth > 1 ? T.max_depth - 1 : 1; S.fc_mask = CS.inline_leaves ? 0x00FFFFFFu : 0xFFFFFFFFu;   // only internal nodes push a frame; the deepest level holds leaves S._pad = 0;
+        S.n_lights = n_lights; S.max_reflection_depth = o.max_reflection_depth; S.stack_levels = T.max_depth > 1 ? T.max_depth - 1 : 1; S.fc_mask = CS.inline_leaves ? 0x00FFFFFFu : 0xFFFFFFFFu;   // (stack_levels: only internal nodes push a frame; the deepest level holds leaves)
         S.origin[0] = origin.x; S.origin[1] = origin.y; S.origin[2] = origin.z;
         S.surface_offset = o.surface_offset;
         for (uint32_t i = 0; i < n_lights; i++) {
@@ -413,6 +426,8 @@ int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n
 #endif
         HIP_TRY(hipEventCreate(&rt->ev0)); HIP_TRY(hipEventCreate(&rt->ev1));
         HIP_TRY(hipDeviceSynchronize());
+        rt->index_ms = std::chrono::duration<double, std::milli>(t_index1 - t_index0).count();
+        rt->upload_ms = std::chrono::duration<double, std::milli>(clk::now() - t_index1).count();
         // Own-list filter variant: forced by a flag, else measured on the first frame of each frame size (tune_variant below)
         rt->variant_forced = (o.flags & (RRT_FLAG_BUNDLE_FILTER | RRT_FLAG_LANE_FILTER | RRT_FLAG_NO_CULL)) != 0;
         rt->bundle = (o.flags & RRT_FLAG_BUNDLE_FILTER) != 0 && !(o.flags & RRT_FLAG_NO_CULL);
@@ -428,6 +443,9 @@ void rrt_raytracer_destroy(rrt_raytracer* rt) {
         (void)hipSetDevice(rt->device);
         for (void* p : rt->allocs) (void)hipFree(p);
         if (rt->host_fb) (void)hipFree(rt->host_fb);
+        if (rt->staging) (void)hipHostFree(rt->staging);
+        for (auto& e : rt->chunk_ev) if (e) (void)hipEventDestroy(e);
+        if (rt->own_stream) (void)hipStreamDestroy(rt->own_stream);
         if (rt->ev0) (void)hipEventDestroy(rt->ev0);
         if (rt->ev1) (void)hipEventDestroy(rt->ev1);
         (void)hipSetDevice(prev);
@@ -481,6 +499,23 @@ int rrt_detile_device(rrt_raytracer* rt, uint32_t width, uint32_t height, uint32
     });
 }
 
+// Page-locks a caller-owned framebuffer (e.g. the Rust host's Canvas.buffer, engine.rs:127) so that rrt_render can DMA the frame straight
+// into it.  Optional: rrt_render works on pageable memory too, through a pinned staging buffer and one extra host copy.
+int rrt_host_buffer_register(void* ptr, size_t bytes) {
+    return guarded([&]() -> int {
+        if (!ptr || !bytes) throw Error{RRT_ERR_INVALID_ARG, "null buffer"};
+        HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+        return RRT_OK;
+    });
+}
+int rrt_host_buffer_unregister(void* ptr) {
+    return guarded([&]() -> int {
+        if (!ptr) throw Error{RRT_ERR_INVALID_ARG, "null buffer"};
+        HIP_TRY(hipHostUnregister(ptr));
+        return RRT_OK;
+    });
+}
+
 int rrt_render(rrt_raytracer* rt, uint32_t width, uint32_t height, uint32_t* out_fb) {
     return guarded([&]() -> int {
         check_frame(rt, width, height);
@@ -492,9 +527,38 @@ int rrt_render(rrt_raytracer* rt, uint32_t width, uint32_t height, uint32_t* out
             HIP_TRY(hipMalloc(&rt->host_fb, bytes));
             rt->host_fb_bytes = bytes;
         }
-        const int rc = rrt_render_device(rt, width, height, rt->host_fb, nullptr);
+        if (!rt->own_stream) HIP_TRY(hipStreamCreateWithFlags(&rt->own_stream, hipStreamNonBlocking));
+        const int rc = rrt_render_device(rt, width, height, rt->host_fb, rt->own_stream);
         if (rc != RRT_OK) return rc;
-        HIP_TRY(hipMemcpy(out_fb, rt->host_fb, bytes, hipMemcpyDeviceToHost));   // blocking: the frame is in out_fb on return
+        // Is the caller's framebuffer page-locked (rrt_host_buffer_register, hipHostMalloc, ...)?  Then one asynchronous DMA into it.
+        hipPointerAttribute_t attr{};
+        const bool pinned = hipPointerGetAttributes(&attr, out_fb) == hipSuccess && attr.type == hipMemoryTypeHost;
+        if (!pinned) (void)hipGetLastError();
+        if (pinned) {
+            HIP_TRY(hipMemcpyAsync(out_fb, rt->host_fb, bytes, hipMemcpyDeviceToHost, rt->own_stream));
+            HIP_TRY(hipStreamSynchronize(rt->own_stream));                 // blocking: the frame is in out_fb on return
+            return RRT_OK;
+        }
+        // Pageable framebuffer: DMA into pinned staging in row chunks and copy each chunk out while the next ones are still in flight
+        // (a pageable hipMemcpy stages through the runtime's own bounce buffers serially: 2.3 ms per 1080p frame against 1.0 ms of tracing).
+        if (rt->staging_bytes < bytes) {
+            if (rt->staging) { (void)hipHostFree(rt->staging); rt->staging = nullptr; rt->staging_bytes = 0; }
+            HIP_TRY(hipHostMalloc(&rt->staging, bytes, hipHostMallocDefault));
+            rt->staging_bytes = bytes;
+        }
+        for (auto& e : rt->chunk_ev) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        const int n_chunks = bytes >= (size_t)(1u << 20) ? rrt_raytracer::kCopyChunks : 1;
+        const size_t rows_per = ((size_t)height + n_chunks - 1) / n_chunks, row_bytes = sizeof(uint32_t) * (size_t)width;
+        for (int c = 0; c < n_chunks; c++) {
+            const size_t r0 = std::min<size_t>(height, c * rows_per), r1 = std::min<size_t>(height, (c + 1) * rows_per);
+            if (r1 > r0) HIP_TRY(hipMemcpyAsync((char*)rt->staging + r0 * row_bytes, (const char*)rt->host_fb + r0 * row_bytes, (r1 - r0) * row_bytes, hipMemcpyDeviceToHost, rt->own_stream));
+            HIP_TRY(hipEventRecord(rt->chunk_ev[c], rt->own_stream));
+        }
+        for (int c = 0; c < n_chunks; c++) {
+            const size_t r0 = std::min<size_t>(height, c * rows_per), r1 = std::min<size_t>(height, (c + 1) * rows_per);
+            HIP_TRY(hipEventSynchronize(rt->chunk_ev[c]));
+            if (r1 > r0) std::memcpy((char*)out_fb + r0 * row_bytes, (const char*)rt->staging + r0 * row_bytes, (r1 - r0) * row_bytes);
+        }
         return RRT_OK;
     });
 }
@@ -592,6 +656,16 @@ int rrt_prof_counters(rrt_raytracer* rt, unsigned long long* out16) {
     });
 }
 #endif
+
+int rrt_get_setup_times(const rrt_model* m, const rrt_raytracer* rt, rrt_setup_times* out) {
+    return guarded([&]() -> int {
+        if (!out) throw Error{RRT_ERR_INVALID_ARG, "null argument"};
+        std::memset(out, 0, sizeof *out);
+        if (m) { out->read_ms = m->m.read_ms; out->parse_ms = m->m.parse_ms; out->texture_ms = m->m.texture_ms; out->octree_ms = m->m.octree_ms; }
+        if (rt) { out->index_ms = rt->index_ms; out->upload_ms = rt->upload_ms; }
+        return RRT_OK;
+    });
+}
 
 int rrt_last_stats(const rrt_raytracer* rt_c, rrt_stats* out) {
     return guarded([&]() -> int {

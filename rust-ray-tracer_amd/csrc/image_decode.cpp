@@ -214,8 +214,10 @@ void decode_jpeg(const std::vector<uint8_t>& buf, std::vector<uint8_t>& out, uin
             for (auto& c : comps) {
                 int32_t blk[64] = {};
                 int t = decode_symbol(br, dc[c.td]);
+                if (t > 11) fail(RRT_ERR_PARSE, "Cannot decode texture file: bad DC category");          // 8-bit JPEG: DC differences have at most 11 bits
                 int diff = t ? extend(br.bits(t), t) : 0;
                 c.pred += diff;
+                if (c.pred < -32768 || c.pred > 32767) fail(RRT_ERR_PARSE, "Cannot decode texture file: DC predictor out of range");
                 blk[0] = c.pred * qt[c.tq][0];
                 for (int k = 1; k < 64;) {
                     int rs = decode_symbol(br, ac[c.ta]);
@@ -224,9 +226,11 @@ void decode_jpeg(const std::vector<uint8_t>& buf, std::vector<uint8_t>& out, uin
                     k += r;
                     if (k > 63) fail(RRT_ERR_PARSE, "Cannot decode texture file: bad AC run");
                     int z = kZigzag[k];
+                    if (sz > 10) fail(RRT_ERR_PARSE, "Cannot decode texture file: bad AC size");                // 8-bit JPEG: AC coefficients have at most 10 bits
                     blk[z] = extend(br.bits(sz), sz) * qt[c.tq][z];
                     k++;
                 }
+                for (int k = 0; k < 64; k++) blk[k] = blk[k] < -(1 << 15) ? -(1 << 15) : blk[k] > (1 << 15) ? (1 << 15) : blk[k];   // hostile tables: keep the IDCT inside int32 (a valid file never gets near)
                 idct_islow(blk, c.plane.data() + (size_t)by * 8 * stride + (size_t)bx * 8, stride);
             }
             if (restart_interval) to_restart--;
@@ -257,6 +261,7 @@ void decode_jpeg(const std::vector<uint8_t>& buf, std::vector<uint8_t>& out, uin
 }
 
 // ===================================================================== PNG
+constexpr uint32_t kMaxImageDim = 65535;   // JPEG's own limit; the `image` crate enforces limits of its own on the reference side
 uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 
 void decode_png(const std::vector<uint8_t>& buf, std::vector<uint8_t>& out, uint32_t& W, uint32_t& H, uint32_t& channels) {
@@ -275,6 +280,7 @@ void decode_png(const std::vector<uint8_t>& buf, std::vector<uint8_t>& out, uint
         i += 12 + (size_t)len;
     }
     if (ctype < 0 || W == 0 || H == 0) fail(RRT_ERR_PARSE, "Cannot decode texture file: bad PNG header");
+    if (W > kMaxImageDim || H > kMaxImageDim) fail(RRT_ERR_PARSE, "Cannot decode texture file: PNG dimensions beyond the supported 65535 x 65535");   // (row+1)*H below must not wrap
     if (depth != 8 || interlace != 0 || trns) fail(RRT_ERR_UNSUPPORTED, "PNG: only 8-bit, non-interlaced, no tRNS");
     int src_ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!src_ch) fail(RRT_ERR_PARSE, "Cannot decode texture file: bad PNG colour type");

@@ -42,6 +42,7 @@ struct Model {
     std::vector<Texture> textures;
     Box root{};
     FlatOctree tree;
+    double read_ms = 0, parse_ms = 0, texture_ms = 0, octree_ms = 0;   // wall time of the set-up stages (reported by rrt_get_setup_times)
 };
 
 // octree.cpp

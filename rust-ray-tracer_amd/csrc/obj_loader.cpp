@@ -2,6 +2,7 @@
 // Same directive set, same defaults and the same failure points; a reference `expect`/`unwrap`/`assert!` panic
 // becomes rrt::Error{RRT_ERR_PARSE|RRT_ERR_IO} carried back over the C ABI as a status code.
 #include <charconv>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <fstream>
@@ -102,7 +103,9 @@ struct Loader {
 
     uint32_t load_texture(const std::string& name) {   // get_texture_from_file_name, utils.rs:345-368
         std::vector<uint8_t> bytes; uint32_t w = 0, h = 0, ch = 0;
+        const auto t0 = std::chrono::steady_clock::now();
         decode_image_file(dir + name, bytes, w, h, ch);
+        m.texture_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         // utils.rs:353 walks `as_bytes().chunks(3)` whatever the colour type; only a 3-byte-per-pixel buffer gives
         // width*height colours, anything else indexes out of bounds later (raytracer.rs:55).  Refuse it here.
         if (ch != 3) fail(RRT_ERR_UNSUPPORTED, "texture '" + name + "' is not 3 bytes per pixel");
@@ -239,10 +242,18 @@ void load_obj(const std::string& obj_path, const Box& root, Model& out) {
     out.root = root;
     size_t slash = obj_path.find_last_of('/');
     Loader L{slash == std::string::npos ? std::string() : obj_path.substr(0, slash + 1), out, {}, {}, {}, {}};
-    L.parse_obj(read_file(obj_path));
+    using clk = std::chrono::steady_clock;
+    auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t0 = clk::now();
+    const std::string text = read_file(obj_path);
+    const auto t1 = clk::now();
+    L.parse_obj(text);
+    const auto t2 = clk::now();
     // the reference pushes each triangle into the octree as it is parsed (utils.rs:196); inserting them afterwards
     // in the same order builds the same tree
     build_octree(out.triangles, out.root, out.tree);
+    const auto t3 = clk::now();
+    out.read_ms = ms(t0, t1); out.parse_ms = ms(t1, t2) - out.texture_ms; out.octree_ms = ms(t2, t3);
 }
 
 }  // namespace rrt

@@ -37,19 +37,48 @@ def soup_arrays(n_tris: int, seed: int, s: float = 0.05):
     return verts, vt, nrm
 
 
-def write_soup_obj(path: str, n_tris: int, seed: int, mtllib: str = "materials.mtl", material: str = "teapot") -> str:
-    """Writes the soup as a .obj next to `mtllib` (texture names resolve against the .obj's directory)."""
+def _faces(lo: int, hi: int) -> np.ndarray:
+    i = np.arange(lo, hi, dtype=np.int64)
+    return np.stack([3 * i + 1, 3 * i + 1, i + 1, 3 * i + 2, 3 * i + 2, i + 1, 3 * i + 3, 3 * i + 3, i + 1], -1)
+
+
+def _write_part(base: str, n_tris: int, seed: int, k: int, parts: int) -> None:
+    """Worker k of `parts`: the text of triangles [lo, hi) of each of the four sections, one part file per section."""
     verts, vt, nrm = soup_arrays(n_tris, seed)
-    tmp = path + ".tmp"
-    with open(tmp, "w") as f:
-        f.write(f"# synthetic soup: {n_tris} triangles, splitmix64 seed {seed:#x}\nmtllib {mtllib}\n")
-        np.savetxt(f, verts.reshape(-1, 3), fmt="v %.6f %.6f %.6f")
-        np.savetxt(f, vt.reshape(-1, 2), fmt="vt %.6f %.6f")
-        np.savetxt(f, nrm, fmt="vn %.6f %.6f %.6f")
-        f.write(f"usemtl {material}\n")
-        i = np.arange(n_tris, dtype=np.int64)
-        faces = np.stack([3 * i + 1, 3 * i + 1, i + 1, 3 * i + 2, 3 * i + 2, i + 1, 3 * i + 3, 3 * i + 3, i + 1], -1)
-        np.savetxt(f, faces, fmt="f %d/%d/%d %d/%d/%d %d/%d/%d")
+    lo, hi = n_tris * k // parts, n_tris * (k + 1) // parts
+    np.savetxt(f"{base}.v.{k}", verts[lo:hi].reshape(-1, 3), fmt="v %.6f %.6f %.6f")
+    np.savetxt(f"{base}.vt.{k}", vt[lo:hi].reshape(-1, 2), fmt="vt %.6f %.6f")
+    np.savetxt(f"{base}.vn.{k}", nrm[lo:hi], fmt="vn %.6f %.6f %.6f")
+    np.savetxt(f"{base}.f.{k}", _faces(lo, hi), fmt="f %d/%d/%d %d/%d/%d %d/%d/%d")
+
+
+def write_soup_obj(path: str, n_tris: int, seed: int, mtllib: str = "materials.mtl", material: str = "teapot", workers: int | None = None) -> str:
+    """Writes the soup as a .obj next to `mtllib` (texture names resolve against the .obj's directory).  Formatting 12 M numbers is the slow part,
+    so large soups are formatted by `workers` fresh interpreter processes (this file run as a script: numpy only, nothing that touches a GPU),
+    each writing its slice of every section; the parts are concatenated in order, so the bytes do not depend on the worker count."""
+    import shutil
+    import subprocess
+    import sys
+    if workers is None:
+        workers = 1 if n_tris < 200000 else max(1, min(16, (os.cpu_count() or 1)))
+    tmp = path + f".tmp{os.getpid()}"
+    if workers == 1:
+        _write_part(tmp, n_tris, seed, 0, 1)
+    else:
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), tmp, str(n_tris), str(seed), str(k), str(workers)]) for k in range(workers)]
+        rcs = [p.wait() for p in procs]
+        if any(rcs):
+            raise RuntimeError(f"soup writer workers failed: {rcs}")
+    with open(tmp, "wb") as f:
+        f.write(f"# synthetic soup: {n_tris} triangles, splitmix64 seed {seed:#x}\nmtllib {mtllib}\n".encode())
+        for sec in ("v", "vt", "vn", "f"):
+            if sec == "f":
+                f.write(f"usemtl {material}\n".encode())
+            for k in range(workers):
+                part = f"{tmp}.{sec}.{k}"
+                with open(part, "rb") as g:
+                    shutil.copyfileobj(g, f, 1 << 24)
+                os.remove(part)
     os.replace(tmp, path)
     return path
 
@@ -59,3 +88,8 @@ def ensure_soup(assets_dir: str, n_tris: int, seed: int) -> str:
     if not os.path.exists(path):
         write_soup_obj(path, n_tris, seed)
     return path
+
+
+if __name__ == "__main__":          # worker entry of write_soup_obj
+    import sys
+    _write_part(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]))

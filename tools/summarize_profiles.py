@@ -1,7 +1,11 @@
-"""Condenses a tools/collect_profiles.sh output directory into <dir>/<tag>_summary.json (kernel stats + per-launch PMC averages of render_kernel)."""
+"""Condenses a tools/collect_profiles.sh output directory into <dir>/<tag>_summary.json (kernel stats + per-launch PMC averages of render_kernel),
+stamped with the sha256 of the kernel sources the numbers were measured on (bench.py refuses a summary whose stamp does not match its sources)."""
 import collections, csv, glob, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_sha256
 out_dir, tag = sys.argv[1], sys.argv[2]
-summary = {"tag": tag, "kernel": "render_kernel", "pmc_avg_per_launch": {}, "kernel_stats": None}
+bench_args = sys.argv[3] if len(sys.argv) > 3 else ""
+summary = {"tag": tag, "bench_args": bench_args, "source_sha256": kernel_source_sha256(), "kernel": "render_kernel", "pmc_avg_per_launch": {}, "kernel_stats": None}
 dominant = None      # render_kernel<false> (lane filter) and render_kernel<true> (bundle filter) both run while the variant is tuned: keep the one that does the frames
 for f in glob.glob(os.path.join(out_dir, "trace", "*", "*kernel_stats.csv")):
     for r in csv.DictReader(open(f)):
@@ -9,6 +13,11 @@ for f in glob.glob(os.path.join(out_dir, "trace", "*", "*kernel_stats.csv")):
             dominant = r["Name"]
             summary["kernel_stats"] = {k: r[k] for k in ("Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")}
 summary["kernel"] = dominant
+for f in glob.glob(os.path.join(out_dir, "trace", "*", "*kernel_trace.csv")):   # registers / scratch / LDS of the dominant kernel as dispatched
+    for r in csv.DictReader(open(f)):
+        if r.get("Kernel_Name") == dominant:
+            summary["dispatch"] = {k: r[k] for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Grid_Size", "Workgroup_Size") if k in r}
+            break
 for f in glob.glob(os.path.join(out_dir, "pmc_*", "*", "*counter_collection.csv")):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
