@@ -81,7 +81,8 @@ typedef struct {
     uint64_t rays_primary;            /* 4 * pixels actually traced */
     uint64_t scene_bytes;             /* bytes resident in HBM for this raytracer (geometry+octree+textures) */
     uint32_t filter_variant;          /* 0 = LANE filter, 1 = BUNDLE filter (forced, or measured on the first frame of this size) */
-    uint32_t _pad;
+    uint32_t origin_plane_triangles;  /* triangles whose plane contains the raytracer's origin to rounding distance: rays from the origin that lie
+                                       * in such a plane run with the index filters off (exactness guard); 0 for ordinary scenes */
 } rrt_stats;
 
 /* ------------------------------------------------------------------ model = SceneData (scenedata.rs:5-13), host side */

@@ -28,6 +28,7 @@ struct rrt_raytracer {
     bool variant_forced = false;
     void* host_fb = nullptr;         // device framebuffer kept between rrt_render calls (host-buffer entry point)
     size_t host_fb_bytes = 0;
+    uint32_t n_suspects = 0;         // triangles whose plane contains the origin (exactness guard, clusters.cpp)
     double index_ms = 0, upload_ms = 0;  // set-up stages of rrt_raytracer_create
     hipStream_t own_stream = nullptr;   // rrt_render's stream (non-blocking: independent of the legacy default stream)
     void* staging = nullptr;         // pinned host staging for callers whose framebuffer is pageable memory
@@ -166,7 +167,7 @@ void record_launch(rrt_raytracer* rt, uint32_t width, uint32_t height, uint32_t 
     rt->stats.rays_primary = world == 1 ? 4ull * wt * ht : 0;   // per-rank share is not tracked
     (void)rank;
     rt->stats.scene_bytes = rt->scene_bytes;
-    rt->stats.filter_variant = rt->bundle ? 1u : 0u; rt->stats._pad = 0;
+    rt->stats.filter_variant = rt->bundle ? 1u : 0u; rt->stats.origin_plane_triangles = rt->n_suspects;
     rt->stats_pending = true;
 }
 
@@ -409,6 +410,15 @@ int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n
                 for (double v : {d.lo[k], d.mid[k], d.hi[k]})
                     if (!(v == 0.0 || (std::fabs(v) > 0x1p-200 && std::fabs(v) < 0x1p200))) S.bounds_plain = 0u;
         S.cull_limit = (float)(CS.scene_magnitude * 4.0);
+        {   // exactness guard of the index for rays from `origin` (clusters.cpp, find_origin_suspects)
+            std::vector<DevSuspect> sus;
+            const double org[3] = {origin.x, origin.y, origin.z};
+            if (S.cull_enabled) find_origin_suspects(M, org, CS.pad, sus);
+            rt->n_suspects = (uint32_t)sus.size();
+            S.n_suspects = (uint32_t)sus.size();
+            if (sus.size() > RRT_MAX_SUSPECTS) sus.resize(1);              // beyond the cap every ray from the origin runs unfiltered; the list is not read
+            S.suspects = upload(rt.get(), sus.data(), sus.size());
+        }
         S.attr = upload(rt.get(), attr.data(), attr.size());
         S.mats = upload(rt.get(), mats.data(), mats.size());
         S.tex = upload(rt.get(), texs.data(), texs.size());
@@ -679,7 +689,7 @@ int rrt_last_stats(const rrt_raytracer* rt_c, rrt_stats* out) {
             rt->stats.kernel_ms = ms;
             rt->stats_pending = false;
         }
-        rt->stats.filter_variant = rt->bundle ? 1u : 0u;
+        rt->stats.filter_variant = rt->bundle ? 1u : 0u; rt->stats.origin_plane_triangles = rt->n_suspects; rt->stats.scene_bytes = rt->scene_bytes;
         *out = rt->stats;
         return RRT_OK;
     });

@@ -80,6 +80,7 @@ void build_clusters(const Model& m, bool enable_cull, ClusterSet& out) {
     for (int k = 0; k < 3; k++) mag = std::max(mag, std::max(std::fabs(m.root.lo[k]), std::fabs(m.root.hi[k])));
     out.scene_magnitude = mag;
     const double pad = mag * kPadFraction;
+    out.pad = pad;
 
     std::vector<TriBox> boxes;
     std::vector<uint32_t> items;
@@ -190,6 +191,44 @@ void build_clusters(const Model& m, bool enable_cull, ClusterSet& out) {
         }
     }
     for (int i = 0; i < 8; i++) out.child_boxes.push_back(DevClusterBox{});
+}
+
+// ---- exactness guard ------------------------------------------------------------------------------------------------------------------
+// The box filters drop a (ray, triangle) pair when the ray misses the triangle's padded box.  That is exact as long as a pair the reference's
+// Moller-Trumbore (ray.rs:56-94) ACCEPTS has its computed hit point within the padding of the true line -- which fails only when a = e1.(d x e2)
+// is rounding noise, i.e. the ray lies in the triangle's plane.  With eps = 2^-53, R = |o - v1| + max|e|, sin(phi) = |e1 x e2| / (|e1||e2|):
+//   * the computed u, v, t carry absolute errors <= ~64 eps R |d| |e1||e2| / |a| relative to the triangle's extent, so the computed hit point
+//     is within pad/2 of the line whenever |sin(angle(d, plane))| > alpha = 8 * 64 eps R / (pad sin(phi))           (not near-parallel: safe);
+//   * for a near-parallel ray (below alpha) the reference can only accept if also |s.(d x e2)| <= |a| and |d.(s x e1)| <= |a| up to rounding,
+//     which bounds the distance of the ray's ORIGIN from the plane by delta = 2 (alpha R + 64 eps R) / sin(phi).
+// So a ray whose origin is farther than delta from a triangle's plane can never be dropped wrongly.  For the raytracer's origin (every primary
+// ray) the triangles within delta are found here, once; a ray from the origin that is within alpha of parallel to one of their planes runs with
+// the filters off (render.hip, origin_ray_in_suspect_plane).  Degenerate and sliver triangles (sin(phi) -> 0) get alpha >= 1: every direction.
+void find_origin_suspects(const Model& m, const double origin[3], double pad, std::vector<DevSuspect>& out) {
+    out.clear();
+    if (!(pad > 0)) return;
+    const double eps = 0x1p-53;
+    for (uint32_t ti : m.tree.own_idx) {
+        const Triangle& t = m.triangles[ti];
+        const double e1[3] = {t.v2.x - t.v1.x, t.v2.y - t.v1.y, t.v2.z - t.v1.z}, e2[3] = {t.v3.x - t.v1.x, t.v3.y - t.v1.y, t.v3.z - t.v1.z};
+        const double s[3] = {origin[0] - t.v1.x, origin[1] - t.v1.y, origin[2] - t.v1.z};
+        const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+        const double l1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]), l2 = std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
+        const double ln = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]), ls = std::sqrt(s[0] * s[0] + s[1] * s[1] + s[2] * s[2]);
+        if (!(l1 > 0) || !(l2 > 0)) continue;             // a zero edge makes a == 0 exactly for every ray: rejected as parallel (ray.rs:66)
+        if (!std::isfinite(l1 + l2 + ls)) continue;        // non-finite geometry: the filter is off for such magnitudes anyway (cull_limit)
+        const double R = ls + std::max(l1, l2);
+        const double sinphi = ln / (l1 * l2);
+        double alpha, delta;
+        if (!(sinphi > 1e-300)) { alpha = 2.0; delta = INFINITY; }
+        else { alpha = 8.0 * 64.0 * eps * R / (pad * sinphi); delta = 2.0 * (alpha * R + 64.0 * eps * R) / sinphi; }
+        const double rho = ln > 0 ? std::fabs(s[0] * n[0] + s[1] * n[1] + s[2] * n[2]) / ln : 0.0;
+        if (!(rho <= delta)) continue;
+        DevSuspect q{};
+        for (int k = 0; k < 3; k++) q.n[k] = ln > 0 ? n[k] / ln : 0.0;
+        q.alpha2 = alpha >= 1.0 ? 4.0 : alpha * alpha;
+        out.push_back(q);
+    }
 }
 
 }  // namespace rrt

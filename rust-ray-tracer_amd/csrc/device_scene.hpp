@@ -51,6 +51,12 @@ struct DevTexture { const uint8_t* rgb; uint32_t width, height; };              
 struct DevMaterial { double ka[3], kd[3], ks[3], ns, kr; int32_t tex, bump; DevTexture tex_desc, bump_desc; };
 struct DevLight { uint32_t kind, _pad; double intensity; double v[3]; };         // entities.rs:5-9
 
+// Exactness guard of the own-list index: a triangle whose plane contains the raytracer's origin to within rounding-noise
+// distance.  A ray from that origin that is also parallel to the plane to within `alpha` lies IN the plane, the reference's Moller-Trumbore result
+// for the pair is rounding noise, and the box filters -- which assume an accepted pair lies inside the padded box -- are switched off for that ray.
+struct DevSuspect { double n[3]; double alpha2; };   // unit normal of the plane; squared sine threshold (>= 1: every direction)
+#define RRT_MAX_SUSPECTS 64
+
 #define RRT_MAX_LIGHTS 16
 #define RRT_MAX_REFLECT 8
 
@@ -72,6 +78,8 @@ struct DevScene {                // passed to kernels by value (kernarg segment 
     float cull_limit;            // rays with |origin| or |direction| components beyond this (or non-finite) skip the box culling
     uint32_t cull_enabled;
     uint32_t has_groups;         // some own list carries group records (clusters.cpp): launches use the kernel instantiation that handles them
+    uint32_t n_suspects;         // triangles whose plane passes through `origin` (see DevSuspect); more than RRT_MAX_SUSPECTS: every ray from `origin` runs unfiltered
+    const DevSuspect* suspects;
     uint32_t bounds_plain;       // every node plane (lo, mid, hi) is 0 or has magnitude in [2^-200, 2^200]: the walk may share the reciprocal of a ray's direction across its slab quotients (render.hip, RayRcp)
     DevLight lights[RRT_MAX_LIGHTS];
 #ifdef RRT_PROFILE
@@ -115,8 +123,12 @@ struct ClusterSet {
     bool inline_leaves = false;                        // single-triangle leaves are tested at their parents (node_leaf_slot, DevNode::leaf_base)
     uint32_t n_list_slots = 0;                         // slots [0, n_list_slots) belong to own lists (cboxes/tboxes cover these); leaf slots follow
     double scene_magnitude = 0;
+    double pad = 0;                                    // absolute padding of every index box
 };
 constexpr uint32_t kPadSlot = 0xFFFFFFFFu;
 void build_clusters(const Model& m, bool enable_cull, ClusterSet& out);
+// exactness guard: the triangles (of the tree) whose plane contains `origin` to within the distance at which a ray from `origin` can be
+// coplanar-to-rounding with them
+void find_origin_suspects(const Model& m, const double origin[3], double pad, std::vector<DevSuspect>& out);
 
 }  // namespace rrt

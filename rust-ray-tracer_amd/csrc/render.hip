@@ -263,6 +263,22 @@ __device__ __forceinline__ bool slab32(const UBox& b, const Ray32& r) {
     return tmin <= tmax;
 }
 
+// Exactness guard: must the index filter stay off for this ray?  Only rays that start at the raytracer's origin can be
+// flagged (every primary ray does); the list of suspect planes is empty for all but constructed scenes, so this is one scalar branch.
+__device__ __forceinline__ bool origin_ray_in_suspect_plane(const DevScene& S, V3 o, V3 d) {
+    if (S.n_suspects == 0u) return false;
+    const bool from_origin = o.x == S.origin[0] && o.y == S.origin[1] && o.z == S.origin[2];
+    if (S.n_suspects > RRT_MAX_SUSPECTS) return from_origin;
+    const double dd = dot(d, d);
+    bool in_plane = false;
+    for (uint32_t i = 0; i < S.n_suspects; ++i) {
+        const DevSuspect q = S.suspects[i];
+        const double c = (d.x * q.n[0] + d.y * q.n[1]) + d.z * q.n[2];
+        in_plane = in_plane || (c * c <= q.alpha2 * dd);
+    }
+    return from_origin && in_plane;
+}
+
 // ------------------------------------------------------------------------------------------------ developer counters
 #ifdef RRT_PROFILE
 struct Prof { unsigned long long c[16]; unsigned long long t[8]; unsigned long long last; };
@@ -384,7 +400,7 @@ __device__ __forceinline__ uint32_t lane_read(uint32_t v, uint32_t src_lane) { r
 // kBundle selects the own-list filter: false = every lane tests each box against its own ray (64 rays x 1 box per instruction);
 // true = boxes in lanes against the wave's ray bundle (64 boxes x 1 bundle per instruction).  Same results either way.
 template <bool kBundle, bool kGroups>
-__device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stack& stk, bool active, bool any_ok, V3 o, V3 d, double max_t,
+__device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stack& stk, bool active, bool any_ok, bool filter_ok, V3 o, V3 d, double max_t,
                                          double& out_t, uint32_t& out_slot) {
     constexpr bool kLeaf = !kBundle;   // leaf children are tested at their parent by the lane-filter kernel only (measured: the extra code costs the bundle kernel 12 % on the teapot)
     bool done = !active;
@@ -397,7 +413,7 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
     const RRT_CONSTANT DevClusterBox* cboxes = (const RRT_CONSTANT DevClusterBox*)S.cboxes;
     const RRT_CONSTANT DevClusterBox* child_boxes = (const RRT_CONSTANT DevClusterBox*)S.child_boxes;
     const RRT_CONSTANT DevClusterBox* tboxes = (const RRT_CONSTANT DevClusterBox*)S.tboxes;
-    const Ray32 r32 = make_ray32(o, d, S.cull_limit, S.cull_enabled != 0);
+    const Ray32 r32 = make_ray32(o, d, S.cull_limit, S.cull_enabled != 0 && filter_ok);   // filter_ok == false: this lane walks every list in full
     // (lane-filter kernel only: with ~2 slab tests per walk on coherent frames the per-walk set-up costs the bundle-filter kernel what the
     // cheaper quotients save -- measured, rocprofv3 SQ_INSTS_VALU 502.8 M -> 495.6 M per teapot frame but 2 % slower; the soups gain 2 %)
     RayRcp RR; RR.rx = RR.ry = RR.rz = 0.0; RR.plain = false;
@@ -824,11 +840,12 @@ __device__ __forceinline__ uint32_t trace_colour(PROF_DECL const DevScene& S, co
     uint32_t n_eval = 0;                    // lights [0, n_eval) contribute (an occluded point light ends the loop, raytracer.rs:235-237)
     uint32_t term = 0x00FFFFFFu;            // colour of the last segment
     double st_local[RRT_MAX_REFLECT][3]; double st_kr[RRT_MAX_REFLECT];
+    const bool first_unfiltered = origin_ray_in_suspect_plane(S, origin, direction);   // exactness guard for the primary segment (false for all but constructed scenes)
 
     while (__any(live)) {
         double t; uint32_t slot;
         PROF_T(4);                                                       // [4] shading / state machine between traversals
-        traverse<kBundle, kGroups>(PROF_ARG S, stk, live, in_shadow, ro, rd, rmax, t, slot);
+        traverse<kBundle, kGroups>(PROF_ARG S, stk, live, in_shadow, !(first_unfiltered && depth == 0u && !in_shadow), ro, rd, rmax, t, slot);
         if (live) {
             const bool found = slot != kNone;
             if (!in_shadow) {
@@ -1044,7 +1061,7 @@ __global__ __launch_bounds__(64) void intersect_kernel(const DevScene S, uint32_
 #ifdef RRT_PROFILE
     Prof prof{}; prof.last = 0;
 #endif
-    traverse<kBundle, true>(PROF_ARG S, stk, ok, false, o, d, mt, t, slot);
+    traverse<kBundle, true>(PROF_ARG S, stk, ok, false, !origin_ray_in_suspect_plane(S, o, d), o, d, mt, t, slot);
     if (!ok) return;
     if (slot == kNone) { hit[i] = 0; t_out[i] = 0; u_out[i] = 0; v_out[i] = 0; tri_out[i] = kNone; return; }
     double t2, u = 0, v = 0;
