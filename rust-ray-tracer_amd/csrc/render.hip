@@ -99,13 +99,28 @@ __device__ __forceinline__ double quot(double num, double den, double r) {
     return __builtin_amdgcn_div_fixup(q, den, num);
 }
 
+// The scene descriptor arrives in the kernarg segment and hipcc fetches its pointers with one s_load_dwordx16; a value that is a slice of such a
+// 16-SGPR tuple is spilled and reloaded WITH the tuple (16 v_writelane / v_readlane per use of one pointer once SGPRs run short, which they do in
+// the own-list loops: box bursts take 32-64 of the 102).  An empty asm makes each pointer a value of its own, 2 SGPRs, spilled alone.
+template <class T> __device__ __forceinline__ T* own_sgprs(T* p) {
+#ifdef RRT_NO_OWN_SGPRS
+    return p;
+#else
+    unsigned long long r = (unsigned long long)p;
+    asm volatile("" : "+s"(r));
+    return (T*)r;
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------ LDS stack
 // per wave: levels x 768 B, level record = own_slot[64] u32 | meta[64] u32 | fc[64] u32.  A frame does not keep the t of its own hit: the few
 // times an older frame's own hit is compared or returned, t is recomputed from the slot (t_of_slot: same arithmetic, same bits), which
 // keeps the stack at 12 bytes per lane and level so that LDS does not cap the number of resident waves.
 constexpr uint32_t kLevelBytes = 3 * 64 * 4;
+constexpr uint32_t kParkBytes = 64;       // in front of the stack: the wave's ray bundle of the current walk, parked by the lane-filter kernel (see traverse)
 struct Stack {
     char* base; uint32_t lane;
+    __device__ __forceinline__ float* park() const { return reinterpret_cast<float*>(base - kParkBytes); }
     __device__ __forceinline__ uint32_t& own_slot(uint32_t l) const { return *reinterpret_cast<uint32_t*>(base + l * kLevelBytes + lane * 4); }
     __device__ __forceinline__ uint32_t& meta(uint32_t l) const { return *reinterpret_cast<uint32_t*>(base + l * kLevelBytes + 256 + lane * 4); }
     __device__ __forceinline__ uint32_t& fc(uint32_t l) const { return *reinterpret_cast<uint32_t*>(base + l * kLevelBytes + 512 + lane * 4); }
@@ -120,15 +135,24 @@ typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ double mkd(uint32_t lo, uint32_t hi) { return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo); }
 __device__ __forceinline__ float mkf(uint32_t x) { return __builtin_bit_cast(float, x); }
 
-struct UNode { double lo[3], hi[3], mid[3]; uint32_t first_child, sup_begin, sup_count, flags, s0_begin, s0_count, leaf_base; };
-__device__ __forceinline__ UNode load_unode(const RRT_CONSTANT DevNode* p) {
-    const u32x16 a = *(const RRT_CONSTANT u32x16*)p;
+// The node record in two scalar loads: the 32-byte tail (third split plane, child/list descriptors, flags) that every visit needs at once, and the
+// 64-byte head (box and split planes as 8 doubles) that only the exact child slab tests read.  Loading the head after the fp32 reach filter keeps
+// its 16 SGPRs out of the way of the child-box bursts (they were spilled to VGPR lanes and reloaded on every visit: 32 VALU instructions) and
+// skips the load when no child is reachable.
+struct UHead { uint32_t first_child, sup_begin, sup_count, flags, s0_begin, s0_count, leaf_base; double mid2; };
+__device__ __forceinline__ UHead load_uhead(const RRT_CONSTANT DevNode* p) {
     const u32x8 b = *(const RRT_CONSTANT u32x8*)((const RRT_CONSTANT char*)p + 64);
-    UNode n;
+    UHead n;
+    n.mid2 = mkd(b[0], b[1]); n.first_child = b[2]; n.sup_begin = b[3]; n.sup_count = b[4]; n.flags = b[5]; n.s0_begin = b[6]; n.s0_count = b[5] >> 24; n.leaf_base = b[7];
+    return n;
+}
+struct UPlanes { double lo[3], hi[3], mid[3]; };
+__device__ __forceinline__ UPlanes load_uplanes(const RRT_CONSTANT DevNode* p, double mid2) {
+    const u32x16 a = *(const RRT_CONSTANT u32x16*)p;
+    UPlanes n;
     n.lo[0] = mkd(a[0], a[1]); n.lo[1] = mkd(a[2], a[3]); n.lo[2] = mkd(a[4], a[5]);
     n.hi[0] = mkd(a[6], a[7]); n.hi[1] = mkd(a[8], a[9]); n.hi[2] = mkd(a[10], a[11]);
-    n.mid[0] = mkd(a[12], a[13]); n.mid[1] = mkd(a[14], a[15]); n.mid[2] = mkd(b[0], b[1]);
-    n.first_child = b[2]; n.sup_begin = b[3]; n.sup_count = b[4]; n.flags = b[5]; n.s0_begin = b[6]; n.s0_count = b[5] >> 24; n.leaf_base = b[7];
+    n.mid[0] = mkd(a[12], a[13]); n.mid[1] = mkd(a[14], a[15]); n.mid[2] = mid2;
     return n;
 }
 
@@ -337,15 +361,18 @@ __device__ __forceinline__ void wave_min12_f32(float (&x)[12]) {
 // with one origin).  With inv_l in [imin, imax] (same sign) and m_l in [mmin, mmax], a_l(b) lies in (b-c)*[imin,imax] + [mmin,mmax]: an
 // interval that bounds every lane's near/far slab values, so a box whose interval test fails is missed by every lane's own test.
 struct Bundle { float cx, cy, cz, ilx, ihx, ily, ihy, ilz, ihz, mlx, mhx, mly, mhy, mlz, mhz; };
-__device__ __forceinline__ Bundle make_bundle(bool active, V3 o, const Ray32& r) {
+// The rays are anchored at their point of parameter tau: q_l = o_l + tau d_l, and (b - o_l) inv_l = (b - q_l) inv_l + tau.  tau = 0 (the origin) is
+// tight for rays that start together (a primary tile), tau = 1 for shadow rays, which end together at the light (raytracer.rs:170-174: origin + dir
+// = light + 1e-4 n): their origins are spread along the tile's view rays, their far ends are not.
+__device__ __forceinline__ Bundle make_bundle(bool active, V3 o, V3 d, const Ray32& r, float tau) {
     Bundle B;
     const unsigned long long act = __builtin_amdgcn_ballot_w64(active);
     const int leader = act ? __builtin_ctzll(act) : 0;
-    const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
+    const float ox = (float)o.x + tau * (float)d.x, oy = (float)o.y + tau * (float)d.y, oz = (float)o.z + tau * (float)d.z;
     B.cx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ox), leader));
     B.cy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, oy), leader));
     B.cz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, oz), leader));
-    const float mx = (B.cx - ox) * r.ix, my = (B.cy - oy) * r.iy, mz = (B.cz - oz) * r.iz;
+    const float mx = (B.cx - ox) * r.ix + tau, my = (B.cy - oy) * r.iy + tau, mz = (B.cz - oz) * r.iz + tau;
     const float pinf = __builtin_huge_valf();
     // min over the active lanes of x and of -x (max = -min(-x)); inactive lanes hold +inf
     float x[12] = {active ? r.ix : pinf, active ? -r.ix : pinf, active ? r.iy : pinf, active ? -r.iy : pinf, active ? r.iz : pinf, active ? -r.iz : pinf,
@@ -364,6 +391,25 @@ __device__ __forceinline__ Bundle make_bundle(bool active, V3 o, const Ray32& r)
         B.ilx = B.ihx = B.ily = B.ihy = B.ilz = B.ihz = 0.0f; B.mlx = B.mhx = B.mly = B.mhy = B.mlz = B.mhz = 0.0f;
     }
     return B;
+}
+// Is the bundle worth testing boxes against (lane-filter kernel: long own lists switch to boxes in lanes when it is)?  Every axis: directions of
+// one sign, reciprocal directions within 50 % of each other, anchor spread below `slack` in space.  A speed heuristic only: both filters are exact.
+#ifndef RRT_TIGHT_INV
+#define RRT_TIGHT_INV 0.1f
+#endif
+#ifndef RRT_TIGHT_SLACK
+#define RRT_TIGHT_SLACK (1.0f / 16384.0f)
+#endif
+__device__ __forceinline__ bool bundle_is_tight(const Bundle& B, float slack) {
+    bool ok = true;
+#define RRT_TIGHT(il, ih, ml, mh)                                                                               \
+    {                                                                                                           \
+        const float lo = fminf(fabsf(il), fabsf(ih));                                                           \
+        ok = ok && (il > 0.0f) == (ih > 0.0f) && lo > 0.0f && (ih - il) <= RRT_TIGHT_INV * lo && (mh - ml) <= slack * lo;  \
+    }
+    RRT_TIGHT(B.ilx, B.ihx, B.mlx, B.mhx) RRT_TIGHT(B.ily, B.ihy, B.mly, B.mhy) RRT_TIGHT(B.ilz, B.ihz, B.mlz, B.mhz)
+#undef RRT_TIGHT
+    return ok;
 }
 // per-LANE box (lo/hi in VGPRs) against the bundle: false only if no active lane's own slab test could pass
 __device__ __forceinline__ bool bundle_hit(const Bundle& B, float lox, float loy, float loz, float hix, float hiy, float hiz) {
@@ -393,6 +439,49 @@ __device__ __forceinline__ uint32_t wave_compact2(bool keep, uint32_t a, uint32_
 }
 __device__ __forceinline__ uint32_t lane_read(uint32_t v, uint32_t src_lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v); }
 
+// One cluster of an own list (the <= 8 slots from cb0) for the lane-filter kernel: per-triangle boxes (same conservative fp32 filter, one level
+// down), then only the triangles whose box some lane may hit are fetched (80-byte f64 records) and tested.  hc: this lane's ray may hit the cluster.
+__device__ __forceinline__ void own_cluster_lane(PROF_DECL const RRT_CONSTANT DevClusterBox* tboxes, const RRT_CONSTANT DevTriGeom* geom, uint32_t cb0, uint32_t cn, bool hc,
+                                                 const Ray32& r32, V3 o, V3 d, double& own_t, uint32_t& own_slot, uint32_t& own_pos) {
+    const RRT_CONSTANT u32x16* tbx = (const RRT_CONSTANT u32x16*)(tboxes + cb0);
+    uint32_t lane_tri = 0, wave_tri = 0;
+#define RRT_TB(i, v, off)                                                                                                          \
+    if (i < cn) {                                                                                                                  \
+        UBox B; B.lox = mkf(v[off]); B.loy = mkf(v[off + 1]); B.loz = mkf(v[off + 2]);                                             \
+        B.hix = mkf(v[off + 3]); B.hiy = mkf(v[off + 4]); B.hiz = mkf(v[off + 5]); B.a = 0; B.b = 0;                               \
+        const bool h = hc && slab32(B, r32);                                                                                      \
+        PROF_ADD(4, 1);                                                                                                            \
+        lane_tri |= h ? (1u << i) : 0u;                                                                                            \
+        wave_tri |= (__builtin_amdgcn_ballot_w64(h) != 0ull) ? (1u << i) : 0u;                                                     \
+    }
+    {
+        const u32x16 t01 = tbx[0], t23 = tbx[1];
+        RRT_TB(0u, t01, 0) RRT_TB(1u, t01, 8) RRT_TB(2u, t23, 0) RRT_TB(3u, t23, 8)
+    }
+    if (cn > 4u) {
+        const u32x16 t45 = tbx[2], t67 = tbx[3];
+        RRT_TB(4u, t45, 0) RRT_TB(5u, t45, 8) RRT_TB(6u, t67, 0) RRT_TB(7u, t67, 8)
+    }
+#undef RRT_TB
+    if (wave_tri) {
+        uint32_t s = __builtin_ctz(wave_tri);
+        wave_tri &= wave_tri - 1u;
+        UTri tri = load_utri(geom + cb0 + s);
+        for (;;) {
+            const uint32_t s_next = wave_tri ? (uint32_t)__builtin_ctz(wave_tri) : s;
+            UTri nxt = tri;
+            if (wave_tri) nxt = load_utri(geom + cb0 + s_next);                 // scalar prefetch of the next candidate triangle
+            double t;
+            const bool ht = (lane_tri >> s) & 1u;
+            PROF_ADD(2, 1); PROF_ADD(3, __popcll(__ballot(ht)));
+            if (ht && mt_uniform(tri, o, d, t) && (t < own_t || (t == own_t && tri.pos < own_pos))) { own_t = t; own_slot = cb0 + s; own_pos = tri.pos; }
+            if (!wave_tri) break;
+            wave_tri &= wave_tri - 1u;
+            tri = nxt; s = s_next;
+        }
+    }
+}
+
 // Ray::intersect_with_octant_with_max_t(octree, 0, max_t), ray.rs:104-168, for all 64 lanes at once.
 // Must be called from wave-uniform control flow; lanes with active == false take no part.
 // Result: slot == kNone <=> None; otherwise (t, slot) of the returned triangle.
@@ -407,19 +496,44 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
     uint32_t cur = 0;        // node this lane has to enter next
     uint32_t sp = 0;         // number of frames on this lane's stack == depth of `cur`
     double ret_t = kInf; uint32_t ret_slot = kNone;
-    const RRT_CONSTANT DevNode* nodes = (const RRT_CONSTANT DevNode*)S.nodes;
-    const RRT_CONSTANT DevTriGeom* geom = (const RRT_CONSTANT DevTriGeom*)S.geom;
-    const RRT_CONSTANT DevSuper* supers = (const RRT_CONSTANT DevSuper*)S.supers;
-    const RRT_CONSTANT DevClusterBox* cboxes = (const RRT_CONSTANT DevClusterBox*)S.cboxes;
-    const RRT_CONSTANT DevClusterBox* child_boxes = (const RRT_CONSTANT DevClusterBox*)S.child_boxes;
-    const RRT_CONSTANT DevClusterBox* tboxes = (const RRT_CONSTANT DevClusterBox*)S.tboxes;
+    const RRT_CONSTANT DevNode* nodes = (const RRT_CONSTANT DevNode*)own_sgprs(S.nodes);
+    const RRT_CONSTANT DevTriGeom* geom = (const RRT_CONSTANT DevTriGeom*)own_sgprs(S.geom);
+    const RRT_CONSTANT DevSuper* supers = (const RRT_CONSTANT DevSuper*)own_sgprs(S.supers);
+    const RRT_CONSTANT DevClusterBox* cboxes = (const RRT_CONSTANT DevClusterBox*)own_sgprs(S.cboxes);
+    const RRT_CONSTANT DevClusterBox* child_boxes = (const RRT_CONSTANT DevClusterBox*)own_sgprs(S.child_boxes);
+    const RRT_CONSTANT DevClusterBox* tboxes = (const RRT_CONSTANT DevClusterBox*)own_sgprs(S.tboxes);
     const Ray32 r32 = make_ray32(o, d, S.cull_limit, S.cull_enabled != 0 && filter_ok);   // filter_ok == false: this lane walks every list in full
     // (lane-filter kernel only: with ~2 slab tests per walk on coherent frames the per-walk set-up costs the bundle-filter kernel what the
     // cheaper quotients save -- measured, rocprofv3 SQ_INSTS_VALU 502.8 M -> 495.6 M per teapot frame but 2 % slower; the soups gain 2 %)
     RayRcp RR; RR.rx = RR.ry = RR.rz = 0.0; RR.plain = false;
     if constexpr (!kBundle) RR = make_ray_rcp(o, d, S.bounds_plain != 0);
+    // The lane-filter kernel builds the bundle too (about 150 instructions per walk): where the wave's rays form a tight bundle -- a primary tile,
+    // the shadow rays of a tile towards one light -- its LONG own lists (the straddler lists of the upper nodes: thousands of triangles at the root
+    // of a large soup) are searched with boxes in lanes, 64 boxes per instruction, instead of one wave-uniform box at a time.
+#ifndef RRT_BUNDLE_TAU
+#define RRT_BUNDLE_TAU (any_ok ? 1.0f : 0.0f)
+#endif
+#ifndef RRT_HYBRID_MIN_SUPERS
+#define RRT_HYBRID_MIN_SUPERS 2u
+#endif
+#ifndef RRT_HYBRID_MIN_TRIS
+#define RRT_HYBRID_MIN_TRIS 8u
+#endif
     Bundle BU{};
-    if constexpr (kBundle) BU = make_bundle(active, o, r32);
+    bool long_lists_in_lanes = false;
+    if constexpr (kBundle) BU = make_bundle(active, o, d, r32, RRT_BUNDLE_TAU);
+#ifndef RRT_NO_HYBRID
+    if constexpr (!kBundle) {
+        // (parked in LDS rather than held in 15 SGPRs for the whole walk: scalar registers are what the lane-filter kernel is shortest of)
+        const Bundle B0 = make_bundle(active, o, d, r32, any_ok ? 1.0f : 0.0f);
+        long_lists_in_lanes = bundle_is_tight(B0, S.cull_limit * RRT_TIGHT_SLACK);
+        if (stk.lane == 0u) {
+            float* q = stk.park();
+            q[0] = B0.cx; q[1] = B0.cy; q[2] = B0.cz; q[3] = B0.ilx; q[4] = B0.ihx; q[5] = B0.ily; q[6] = B0.ihy; q[7] = B0.ilz; q[8] = B0.ihz;
+            q[9] = B0.mlx; q[10] = B0.mhx; q[11] = B0.mly; q[12] = B0.mhy; q[13] = B0.mlz; q[14] = B0.mhz;
+        }
+    }
+#endif
 
     PROF_ADD(6, 1); PROF_ADD(7, __popcll(__ballot(active)));
     PROF_T(5);                                                           // [5] traverse set-up (ray32) + whatever ran since the last stamp outside
@@ -432,7 +546,7 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
         const int leader = __builtin_ctzll(pending);
         const uint32_t unode = __builtin_amdgcn_readlane(cur, leader);   // wave-uniform node id
 #endif
-        const UNode N = load_unode(nodes + unode);
+        const UHead N = load_uhead(nodes + unode);
         const uint32_t fc = N.first_child, sb = N.sup_begin, sc = N.sup_count, fl = N.flags;
         PROF_ADD(0, 1); PROF_ADD(1, __popcll(__ballot(!done && cur == unode)));
         PROF_T(0);                                                       // [0] pick node + node record load
@@ -471,14 +585,20 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                     // (ray.rs:22-27) is formed ONCE per plane that some reachable child uses (6..9 IEEE divides per node instead of 6 per
                     // child), with the reference's operands, and each child's test is then the reference's min/max on those quotients.
                     // child k = BBL,BFL,BFR,BBR,TBL,TFL,TFR,TBR (octree.rs:216-225): upper x half for k in {2,3,6,7}, y {4..7}, z {1,2,5,6}
+                    UPlanes NP{};
+                    if (reach) {
+                        uint32_t after = reach;                                                            // (an address that depends on the filter's result: the load is issued after it)
+                        asm volatile("s_and_b32 %0, %0, 0" : "+s"(after));
+                        NP = load_uplanes(nodes + unode + after, N.mid2);
+                    }
                     if ((reach & (reach - 1u)) == 0u) {
                         // a single candidate child (the usual case after the reach filter): its six quotients, nothing to sort
                         if (reach) {
                             const uint32_t k = (uint32_t)__builtin_ctz(reach);                           // wave-uniform
                             const bool ux = (0xCCu >> k) & 1u, uy = (0xF0u >> k) & 1u, uz = (0x66u >> k) & 1u;   // upper half per axis
-                            const double clx = ux ? N.mid[0] : N.lo[0], chx = ux ? N.hi[0] : N.mid[0];
-                            const double cly = uy ? N.mid[1] : N.lo[1], chy = uy ? N.hi[1] : N.mid[1];
-                            const double clz = uz ? N.mid[2] : N.lo[2], chz = uz ? N.hi[2] : N.mid[2];
+                            const double clx = ux ? NP.mid[0] : NP.lo[0], chx = ux ? NP.hi[0] : NP.mid[0];
+                            const double cly = uy ? NP.mid[1] : NP.lo[1], chy = uy ? NP.hi[1] : NP.mid[1];
+                            const double clz = uz ? NP.mid[2] : NP.lo[2], chz = uz ? NP.hi[2] : NP.mid[2];
                             double t = kInf;
                             PROF_ADD(8, 1); PROF_ADD(9, __popcll(__ballot(1)));
                             if (lane_reach) {
@@ -502,21 +622,21 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                     } else {
                     double qlx = 0, qmx = 0, qhx = 0, qly = 0, qmy = 0, qhy = 0, qlz = 0, qmz = 0, qhz = 0;
                         if (RR.plain) {
-                            qmx = quot(N.mid[0] - o.x, d.x, RR.rx); qmy = quot(N.mid[1] - o.y, d.y, RR.ry); qmz = quot(N.mid[2] - o.z, d.z, RR.rz);
-                            if (reach & 0x33u) qlx = quot(N.lo[0] - o.x, d.x, RR.rx);
-                            if (reach & 0xCCu) qhx = quot(N.hi[0] - o.x, d.x, RR.rx);
-                            if (reach & 0x0Fu) qly = quot(N.lo[1] - o.y, d.y, RR.ry);
-                            if (reach & 0xF0u) qhy = quot(N.hi[1] - o.y, d.y, RR.ry);
-                            if (reach & 0x99u) qlz = quot(N.lo[2] - o.z, d.z, RR.rz);
-                            if (reach & 0x66u) qhz = quot(N.hi[2] - o.z, d.z, RR.rz);
+                            qmx = quot(NP.mid[0] - o.x, d.x, RR.rx); qmy = quot(NP.mid[1] - o.y, d.y, RR.ry); qmz = quot(NP.mid[2] - o.z, d.z, RR.rz);
+                            if (reach & 0x33u) qlx = quot(NP.lo[0] - o.x, d.x, RR.rx);
+                            if (reach & 0xCCu) qhx = quot(NP.hi[0] - o.x, d.x, RR.rx);
+                            if (reach & 0x0Fu) qly = quot(NP.lo[1] - o.y, d.y, RR.ry);
+                            if (reach & 0xF0u) qhy = quot(NP.hi[1] - o.y, d.y, RR.ry);
+                            if (reach & 0x99u) qlz = quot(NP.lo[2] - o.z, d.z, RR.rz);
+                            if (reach & 0x66u) qhz = quot(NP.hi[2] - o.z, d.z, RR.rz);
                         } else {
-                            qmx = (N.mid[0] - o.x) / d.x; qmy = (N.mid[1] - o.y) / d.y; qmz = (N.mid[2] - o.z) / d.z;
-                            if (reach & 0x33u) qlx = (N.lo[0] - o.x) / d.x;
-                            if (reach & 0xCCu) qhx = (N.hi[0] - o.x) / d.x;
-                            if (reach & 0x0Fu) qly = (N.lo[1] - o.y) / d.y;
-                            if (reach & 0xF0u) qhy = (N.hi[1] - o.y) / d.y;
-                            if (reach & 0x99u) qlz = (N.lo[2] - o.z) / d.z;
-                            if (reach & 0x66u) qhz = (N.hi[2] - o.z) / d.z;
+                            qmx = (NP.mid[0] - o.x) / d.x; qmy = (NP.mid[1] - o.y) / d.y; qmz = (NP.mid[2] - o.z) / d.z;
+                            if (reach & 0x33u) qlx = (NP.lo[0] - o.x) / d.x;
+                            if (reach & 0xCCu) qhx = (NP.hi[0] - o.x) / d.x;
+                            if (reach & 0x0Fu) qly = (NP.lo[1] - o.y) / d.y;
+                            if (reach & 0xF0u) qhy = (NP.hi[1] - o.y) / d.y;
+                            if (reach & 0x99u) qlz = (NP.lo[2] - o.z) / d.z;
+                            if (reach & 0x66u) qhz = (NP.hi[2] - o.z) / d.z;
                         }
                         double tk[8]; bool vk[8];
 #pragma unroll
@@ -587,18 +707,28 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
         // Boxes in lanes: all 64 lanes work here (wave-uniform control flow), each lane testing ONE box of the current level against the
         // wave's ray bundle; survivors are compacted and expanded to the next level; only the triangles that survive are tested, by the
         // lanes parked at this node.
-        if constexpr (kBundle) {
+        bool in_lanes = kBundle;
+#ifndef RRT_NO_HYBRID
+        if constexpr (!kBundle) in_lanes = long_lists_in_lanes && (sc >= RRT_HYBRID_MIN_SUPERS || N.s0_count > RRT_HYBRID_MIN_TRIS);
+#endif
+        if (in_lanes) {
         if ((fl & 0x100u) && sc) {
             const uint32_t lane = stk.lane, sub = lane & 7u, grp = lane >> 3;
+            Bundle BL = BU;
+            if constexpr (!kBundle) {
+                const float* q = stk.park();
+                BL.cx = q[0]; BL.cy = q[1]; BL.cz = q[2]; BL.ilx = q[3]; BL.ihx = q[4]; BL.ily = q[5]; BL.ihy = q[6]; BL.ilz = q[7]; BL.ihz = q[8];
+                BL.mlx = q[9]; BL.mhx = q[10]; BL.mly = q[11]; BL.mhy = q[12]; BL.mlz = q[13]; BL.mhz = q[14];
+            }
             for (uint32_t s0 = 0; s0 < sc; s0 += 64u) {
                 uint32_t l1a = N.s0_begin, l1b = N.s0_count, n1 = 1;             // a single super-cluster: its slot range is in the node record
                 if (sc > 1u) {
                     const uint32_t si = s0 + lane;
                     bool h = false; uint32_t tb = 0, tn = 0;
                     if (si < sc) {
-                        const DevSuper* P = S.supers + sb + si;
+                        const DevSuper* P = (const DevSuper*)supers + sb + si;
                         tb = P->tri_begin; tn = P->tri_count;
-                        h = (!kGroups || tn != 0u) && bundle_hit(BU, P->lo[0], P->lo[1], P->lo[2], P->hi[0], P->hi[1], P->hi[2]);   // (tn == 0: a group record, clusters.cpp -- the lane-filter kernel's business)
+                        h = (!kGroups || tn != 0u) && bundle_hit(BL, P->lo[0], P->lo[1], P->lo[2], P->hi[0], P->hi[1], P->hi[2]);   // (tn == 0: a group record, clusters.cpp -- the lane-filter kernel's business)
                     }
                     PROF_ADD(10, 1);
                     n1 = wave_compact2(h, tb, tn, lane, l1a, l1b);
@@ -608,8 +738,8 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                     const uint32_t etb = lane_read(l1a, e < n1 ? e : 0u), etn = lane_read(l1b, e < n1 ? e : 0u);
                     bool h2 = false;
                     if (e < n1 && sub * 8u < etn) {
-                        const DevClusterBox* P = S.cboxes + (etb >> 3) + sub;
-                        h2 = bundle_hit(BU, P->lo[0], P->lo[1], P->lo[2], P->hi[0], P->hi[1], P->hi[2]);
+                        const DevClusterBox* P = (const DevClusterBox*)cboxes + (etb >> 3) + sub;
+                        h2 = bundle_hit(BL, P->lo[0], P->lo[1], P->lo[2], P->hi[0], P->hi[1], P->hi[2]);
                     }
                     PROF_ADD(11, 1);
                     uint32_t l2a, l2b;
@@ -619,8 +749,8 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                         const uint32_t fs = lane_read(l2a, f < n2 ? f : 0u), fn = lane_read(l2b, f < n2 ? f : 0u);
                         bool h3 = false;
                         if (f < n2 && sub < fn) {
-                            const DevClusterBox* P = S.tboxes + fs + sub;
-                            h3 = bundle_hit(BU, P->lo[0], P->lo[1], P->lo[2], P->hi[0], P->hi[1], P->hi[2]);
+                            const DevClusterBox* P = (const DevClusterBox*)tboxes + fs + sub;
+                            h3 = bundle_hit(BL, P->lo[0], P->lo[1], P->lo[2], P->hi[0], P->hi[1], P->hi[2]);
                         }
                         PROF_ADD(4, 1);
                         uint32_t l3a, l3b;
@@ -692,45 +822,7 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                             wave_hits &= wave_hits - 1u;
                             const bool hc = (lane_hits >> c) & 1u;
                             const uint32_t cb0 = tb + 8u * c, cn = (tn - 8u * c < 8u) ? tn - 8u * c : 8u;
-                            // per-triangle boxes of this cluster (same conservative fp32 filter, one level down): only triangles whose box some
-                            // lane may hit are fetched (80-byte f64 records) and tested
-                            const RRT_CONSTANT u32x16* tbx = (const RRT_CONSTANT u32x16*)(tboxes + cb0);
-                            uint32_t lane_tri = 0, wave_tri = 0;
-#define RRT_TB(i, v, off)                                                                                                          \
-                            if (i < cn) {                                                                                      \
-                                UBox B; B.lox = mkf(v[off]); B.loy = mkf(v[off + 1]); B.loz = mkf(v[off + 2]);                 \
-                                B.hix = mkf(v[off + 3]); B.hiy = mkf(v[off + 4]); B.hiz = mkf(v[off + 5]); B.a = 0; B.b = 0;   \
-                                const bool h = hc && slab32(B, r32);                                                          \
-                                PROF_ADD(4, 1);                                                                                \
-                                lane_tri |= h ? (1u << i) : 0u;                                                                \
-                                wave_tri |= (__builtin_amdgcn_ballot_w64(h) != 0ull) ? (1u << i) : 0u;                                               \
-                            }
-                            {
-                                const u32x16 t01 = tbx[0], t23 = tbx[1];
-                                RRT_TB(0u, t01, 0) RRT_TB(1u, t01, 8) RRT_TB(2u, t23, 0) RRT_TB(3u, t23, 8)
-                            }
-                            if (cn > 4u) {
-                                const u32x16 t45 = tbx[2], t67 = tbx[3];
-                                RRT_TB(4u, t45, 0) RRT_TB(5u, t45, 8) RRT_TB(6u, t67, 0) RRT_TB(7u, t67, 8)
-                            }
-#undef RRT_TB
-                            if (wave_tri) {
-                                uint32_t s = __builtin_ctz(wave_tri);
-                                wave_tri &= wave_tri - 1u;
-                                UTri tri = load_utri(geom + cb0 + s);
-                                for (;;) {
-                                    const uint32_t s_next = wave_tri ? (uint32_t)__builtin_ctz(wave_tri) : s;
-                                    UTri nxt = tri;
-                                    if (wave_tri) nxt = load_utri(geom + cb0 + s_next);                 // scalar prefetch of the next candidate triangle
-                                    double t;
-                                    const bool ht = (lane_tri >> s) & 1u;
-                                    PROF_ADD(2, 1); PROF_ADD(3, __popcll(__ballot(ht)));
-                                    if (ht && mt_uniform(tri, o, d, t) && (t < own_t || (t == own_t && tri.pos < own_pos))) { own_t = t; own_slot = cb0 + s; own_pos = tri.pos; }
-                                    if (!wave_tri) break;
-                                    wave_tri &= wave_tri - 1u;
-                                    tri = nxt; s = s_next;
-                                }
-                            }
+                            own_cluster_lane(PROF_ARG tboxes, geom, cb0, cn, hc, r32, o, d, own_t, own_slot, own_pos);
                         }
                     }
                     SP = SN;
@@ -766,11 +858,11 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                         if (!(((fcw & ~fcm) >> (24u + k)) & 1u)) { cur = (fcw & fcm) + k; break; }
                         // a leaf child whose triangle this ray hits (tested at the parent, above): it returns Some(t, triangle) without a visit;
                         // a leaf's own record holds its dense slot in leaf_base (it has no children to describe)
-                        ret_slot = S.nodes[(fcw & fcm) + k].leaf_base;
-                        ret_t = t_of_slot(S.geom + ret_slot, o, d);
+                        ret_slot = ((const DevNode*)nodes)[(fcw & fcm) + k].leaf_base;
+                        ret_t = t_of_slot((const DevTriGeom*)geom + ret_slot, o, d);
                     } else {
                         ret_slot = stk.own_slot(sp - 1);                     // no child hit: child_dist = inf -> own (ray.rs:163-167)
-                        ret_t = (ret_slot != kNone) ? t_of_slot(S.geom + ret_slot, o, d) : kInf;
+                        ret_t = (ret_slot != kNone) ? t_of_slot((const DevTriGeom*)geom + ret_slot, o, d) : kInf;
                         sp--;
                     }
                     returning = true;
@@ -778,7 +870,7 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                 if (sp == 0) { done = true; break; }
                 if (ret_slot != kNone) {                                 // a child returned Some -> `break` (ray.rs:155-160), then ray.rs:163-167
                     const uint32_t ps = stk.own_slot(sp - 1);               // the parent's `closest`: its own hit's t, else its threshold (ray.rs:117)
-                    const double pt = (ps != kNone) ? t_of_slot(S.geom + ps, o, d) : ((sp == 1) ? max_t : kInf);
+                    const double pt = (ps != kNone) ? t_of_slot((const DevTriGeom*)geom + ps, o, d) : ((sp == 1) ? max_t : kInf);
                     if (!(ret_t < pt)) { ret_t = pt; ret_slot = ps; }
                     sp--;
                 } else {
@@ -981,7 +1073,7 @@ template <bool kBundle, bool kGroups>
 __global__ __launch_bounds__(64, kBundle ? RRT_WAVES_BUNDLE : RRT_WAVES_LANE) void render_kernel(const DevScene S, const FrameParams F, uint32_t* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const uint32_t lane = threadIdx.x;
-    const Stack stk{lds, lane};
+    const Stack stk{lds + kParkBytes, lane};
     const uint32_t local_tile = blockIdx.x >> 2, quad = blockIdx.x & 3u;
     const uint32_t tile = F.tile_begin + local_tile * F.world + F.rank;
     const uint32_t pix = lane >> 2, sub = lane & 3u;
@@ -1036,7 +1128,7 @@ template <bool kBundle>
 __global__ __launch_bounds__(64) void ray_colour_kernel(const DevScene S, uint32_t n, const double* __restrict__ origins, const double* __restrict__ dirs,
                                                         uint32_t* __restrict__ colours) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const Stack stk{lds, threadIdx.x};
+    const Stack stk{lds + kParkBytes, threadIdx.x};
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     const bool ok = i < n;
     const V3 o = ok ? ld3(origins + 3 * (size_t)i) : mk(0, 0, 0), d = ok ? ld3(dirs + 3 * (size_t)i) : mk(0, 0, 1);
@@ -1052,7 +1144,7 @@ __global__ __launch_bounds__(64) void intersect_kernel(const DevScene S, uint32_
                                                        const double* __restrict__ max_t, uint8_t* __restrict__ hit, double* __restrict__ t_out,
                                                        double* __restrict__ u_out, double* __restrict__ v_out, uint32_t* __restrict__ tri_out) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const Stack stk{lds, threadIdx.x};
+    const Stack stk{lds + kParkBytes, threadIdx.x};
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     const bool ok = i < n;
     const V3 o = ok ? ld3(origins + 3 * (size_t)i) : mk(0, 0, 0), d = ok ? ld3(dirs + 3 * (size_t)i) : mk(0, 0, 1);
@@ -1071,12 +1163,51 @@ __global__ __launch_bounds__(64) void intersect_kernel(const DevScene S, uint32_
 
 }  // namespace
 
-uint32_t stack_bytes_per_wave(uint32_t levels) { return levels * kLevelBytes; }
+uint32_t stack_bytes_per_wave(uint32_t levels) { return kParkBytes + levels * kLevelBytes; }
+
+#ifdef RRT_DEV_HSACO
+// Developer build only (tools/bbprof.py): launch the render kernels from an external code object (the product's own assembly with a counter per
+// basic block) and append the block counts of every launch to a text file.  Never compiled into librrt_hip.so.
+}  // namespace rrt
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+namespace rrt {
+static int dev_hsaco_launch(const DevScene& s, const FrameParams& f, uint32_t* d_out, hipStream_t stream, bool bundle, dim3 grid, uint32_t lds) {
+    static hipModule_t mod = nullptr; static uint32_t* d_cnt = nullptr;
+    constexpr size_t kCnt = 16 * 64;
+    if (!mod) {
+        if (hipModuleLoad(&mod, getenv("RRT_DEV_HSACO")) != hipSuccess) { fprintf(stderr, "RRT_DEV_HSACO: cannot load %s\n", getenv("RRT_DEV_HSACO")); abort(); }
+        if (hipMalloc((void**)&d_cnt, kCnt * 4) != hipSuccess) abort();
+    }
+    char name[160];
+    snprintf(name, sizeof name, "_ZN3rrt12_GLOBAL__N_113render_kernelILb%dELb%dEEEvNS_8DevSceneENS_11FrameParamsEPj", bundle ? 1 : 0, s.has_groups ? 1 : 0);
+    hipFunction_t fn;
+    if (hipModuleGetFunction(&fn, mod, name) != hipSuccess) { fprintf(stderr, "RRT_DEV_HSACO: no kernel %s\n", name); abort(); }
+    struct Args { DevScene s; FrameParams f; uint32_t* out; } a{s, f, d_out};
+    a.s.tex = reinterpret_cast<const DevTexture*>(d_cnt);            // the kernels never read DevScene::tex (texture descriptors are inline in the materials)
+    (void)hipMemsetAsync(d_cnt, 0, kCnt * 4, stream);
+    size_t size = sizeof a;
+    void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    hipError_t e = hipModuleLaunchKernel(fn, grid.x, 1, 1, 64, 1, 1, lds, stream, nullptr, cfg);
+    if (e != hipSuccess) return (int)e;
+    std::vector<uint32_t> h(kCnt);
+    if (hipStreamSynchronize(stream) != hipSuccess || hipMemcpy(h.data(), d_cnt, kCnt * 4, hipMemcpyDeviceToHost) != hipSuccess) return (int)hipGetLastError();
+    if (const char* path = getenv("RRT_DEV_BBPROF_OUT")) {
+        FILE* fp = fopen(path, "a");
+        if (fp) { fprintf(fp, "%s", name); for (uint32_t v : h) fprintf(fp, " %u", v); fprintf(fp, "\n"); fclose(fp); }
+    }
+    return 0;
+}
+#endif
 
 int launch_render(const DevScene& s, const FrameParams& f, uint32_t* d_out, void* stream, bool bundle) {
     const uint32_t n_tiles = f.tile_end > f.tile_begin ? f.tile_end - f.tile_begin : 0u;
     const uint32_t local_tiles = (n_tiles + f.world - 1) / f.world;
     if (local_tiles == 0) return 0;
+#ifdef RRT_DEV_HSACO
+    if (getenv("RRT_DEV_HSACO")) return dev_hsaco_launch(s, f, d_out, (hipStream_t)stream, bundle, dim3(local_tiles * 4), stack_bytes_per_wave(s.stack_levels));
+#endif
     // (four instantiations: the group-record handling of long own lists, clusters.cpp, is compiled in only for scenes that have such lists --
     // its few instructions in the super-cluster loop cost the other scenes 5 % through register allocation alone, measured)
     const dim3 grid(local_tiles * 4), block(64);
