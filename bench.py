@@ -82,6 +82,8 @@ def main() -> None:
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scene", default=os.path.join(ROOT, "assets", "model2.obj"))
     ap.add_argument("--pipeline-depth", type=int, default=4, help="N > 1: frames in flight (gather + de-tiling of a frame overlap the tracing of the next); 0 = plain one-frame-at-a-time step")
+    ap.add_argument("--gather", choices=("lib", "torch"), default="lib", help="N > 1: `lib` = the library's own RCCL gather (rrt_dist_create / rrt_multi_enqueue: partition, gather "
+                    "and de-tiling behind the C ABI); `torch` = the same choreography issued from here with torch.distributed.gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-fb", action="store_true", help="skip the boundary-inclusive rrt_render timings (frame_ms_host_fb)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the bounded cpu_baseline leg (3 samples)")
@@ -166,6 +168,25 @@ def main() -> None:
         tpr = rrt.tiles_per_rank(W, H, world)
         want_pipeline = args.pipeline_depth > 0
         DEPTH = max(1, args.pipeline_depth)
+        use_lib = args.gather == "lib" and not rehearsal
+        lib_mg = None
+        if use_lib:
+            # (a) local: bind RCCL inside the library (dlopen) -- no communication yet; the ranks agree before the collective ncclCommInitRank
+            ok = 1
+            try:
+                uid = rrt.MultiGpu.unique_id()
+            except Exception as e:                                                       # noqa: BLE001
+                ok = 0; pipeline_error = f"rank {rank}: {type(e).__name__}: {e}"
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                use_lib = False; pipeline_fallback = True
+                pipeline_error = pipeline_error or "another rank could not bind RCCL inside the library"
+                print(f"[bench rank {rank}] library gather unavailable ({pipeline_error}); using the torch.distributed gather", file=sys.stderr, flush=True)
+            else:
+                idt = torch.frombuffer(bytearray(uid), dtype=torch.uint8).cuda()
+                dist.broadcast(idt, src=0)
+                lib_mg = rrt.MultiGpu.dist(rt, rank, world, bytes(idt.cpu().numpy().tobytes()), frames_in_flight=DEPTH)   # collective
         ok = 1
         try:
             # Frames in flight: frame i's gather (RCCL stream) and de-tiling (side stream on GPU 0) overlap the tracing of frame i+1, so each of
@@ -233,9 +254,14 @@ def main() -> None:
                     if i is not None: gather_ev[i][1].record(side)
                     detile_done[b].record(side); detile_pending[b] = True
 
+        lib_enqueue = lib_mg.bind_enqueue(fb if rank == 0 else None, W, H) if lib_mg is not None else None
+
+        def lib_step(i):
+            lib_enqueue()                                        # trace -> grouped RCCL send/recv to rank 0 -> de-tile, all enqueued inside the library
+
         def step(i):
             try:
-                simple_step(i) if simple[0] else pipelined_step(i)
+                lib_step(i) if lib_mg is not None else simple_step(i) if simple[0] else pipelined_step(i)
             except Exception as e:                               # noqa: BLE001 -- collectives are in flight: no safe fallback from here
                 print(f"[bench rank {rank}] step failed after collectives were issued ({type(e).__name__}: {e}); aborting", file=sys.stderr, flush=True)
                 try:
@@ -245,6 +271,7 @@ def main() -> None:
 
         def fence():
             set_stream(default_stream)
+            if lib_mg is not None: lib_mg.sync()
             for w in gather_work:
                 if w is not None: w.wait()
             torch.cuda.synchronize()
@@ -253,7 +280,7 @@ def main() -> None:
 
         # one full pipelined step per slot, then agree again: a rank whose pipelined choreography misbehaves WITHOUT raising (wrong frame) cannot be
         # detected here, but a rank that sees an error state on its streams can still vote for the plain step before the timed region
-        if not simple[0]:
+        if not simple[0] or lib_mg is not None:
             for _ in range(DEPTH): step(None)
             fence()
             ok = 1
@@ -277,7 +304,10 @@ def main() -> None:
     host_enqueue_ms = (time.perf_counter() - t0) / args.steps * 1e3   # host time to issue one step (launch + gather + de-tile calls), before any waiting
     fence()
     elapsed = time.perf_counter() - t0
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))   # trace kernel only, HIP events on its launch stream
+    if multi and lib_mg is not None:
+        kernel_ms = float(rt.last_stats()["kernel_ms"])             # library path: HIP events around the rank's last trace launch, on its slot's stream
+    else:
+        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))   # trace kernel only, HIP events on its launch stream
     kernel_ms_min = kernel_ms_max = kernel_ms
     gather_ms = None
     if multi:
@@ -285,7 +315,9 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms_max, kernel_ms_min = float(t[0]), float(t[1]), -float(t[2])
         kernel_ms = kernel_ms_max
-        if rank == 0 and gather_ev and not simple[0] and not rehearsal:
+        if rank == 0 and lib_mg is not None:
+            gather_ms = lib_mg.last_gather_ms()                      # rank 0's stream: own tiles traced -> frame de-tiled (wait for the slowest peer + gather + de-tile), last frame
+        elif rank == 0 and gather_ev and not simple[0] and not rehearsal:
             gather_ms = float(np.mean([a.elapsed_time(b) for a, b in gather_ev]))   # side stream: wait for the RCCL gather of the slot + de-tile
 
     if rank == 0:
@@ -425,13 +457,13 @@ def main() -> None:
                "data": "reference scene assets/model2.obj (teapot+table+mirror, 6334 triangles), camera/lights of main.rs" if teapot else f"synthetic ({scene_name}: SURVEY.md 8d soup recipe)" if scene_name.startswith("soup") else f"reference scene {scene_name}",
                "config": {"workload": f"{scene_name} {W}x{H}, 4 sub-samples/pixel, shadow rays + depth-5 mirror reflection, f64",
                           "rays_primary_per_frame": rays_primary,
-                          "partition": "single launch" if not multi else f"8x8-pixel tiles round-robin over {world} GPUs + RCCL gather to GPU 0, " + ("one frame at a time" if simple[0] else f"{DEPTH} frames in flight (one stream per slot)"),
+                          "partition": "single launch" if not multi else f"8x8-pixel tiles round-robin over {world} GPUs + RCCL gather to GPU 0, " + (f"inside the library (rrt_multi_enqueue), {DEPTH} frames in flight" if lib_mg is not None else "torch.distributed.gather, " + ("one frame at a time" if simple[0] else f"{DEPTH} frames in flight (one stream per slot)")),
                           "octree_nodes": sd.info["n_nodes"], "triangles": sd.info["n_tris"], "filter_variant": "bundle" if rt.last_stats()["filter_variant"] else "lane"},
                "frame_ms": round(ms_per_step, 4), "kernel_ms": round(kernel_ms, 4), "host_enqueue_ms_per_step": round(host_enqueue_ms, 4), "setup_ms": setup,
                **({"rehearsal": "gloo on one GPU: NOT a benchmark result"} if rehearsal else {}),
                "frame_checksum": int(np.bitwise_xor.reduce(frame.ravel().astype(np.uint64) * np.arange(1, frame.size + 1, dtype=np.uint64)))}
         if multi:
-            out.update({"pipeline_fallback": pipeline_fallback, "pipeline_error": pipeline_error, "kernel_ms_per_rank_min": round(kernel_ms_min, 4),
+            out.update({"gather": "lib" if lib_mg is not None else "torch", "pipeline_fallback": pipeline_fallback, "pipeline_error": pipeline_error, "kernel_ms_per_rank_min": round(kernel_ms_min, 4),
                         "kernel_ms_per_rank_max": round(kernel_ms_max, 4), "gather_ms": round(gather_ms, 4) if gather_ms is not None else None})
         if host_fb is not None:
             out.update({"frame_ms_host_fb": host_fb["frame_ms_host_fb"], "host_fb": host_fb})

@@ -148,6 +148,29 @@ int rrt_render_tiles_device(rrt_raytracer *rt, uint32_t width, uint32_t height, 
 int rrt_detile_device(rrt_raytracer *rt, uint32_t width, uint32_t height, uint32_t world, const void *d_gathered,
                       void *d_fb, void *stream);
 
+/* ------------------------------------------------------------------ the N GPUs of one node
+ * The gather is inside the library: grouped RCCL point-to-point sends to rank 0 (every peer on its own xGMI link) and de-tiling on rank 0's GPU.
+ * rrt_multi_create: ONE process drives all GPUs -- the Rust host creates one raytracer per device (rrt_raytracer_create(..., device = i, ...)) and
+ *   hands them over; rts[0]'s device receives the frame.  Uses ncclCommInitAll; RCCL is loaded on first use (dlopen), not at link time.
+ * rrt_dist_create: ONE process per GPU (MPI / torch.distributed style): rank 0 calls rrt_dist_unique_id, the caller ships the 128 bytes to every rank
+ *   by its own means, every rank calls rrt_dist_create (collective: ncclCommInitRank).
+ * frames_in_flight (1..8) sizes a ring of slots, each with its own streams and buffers: rrt_multi_enqueue returns as soon as trace -> gather ->
+ * de-tile of the frame are enqueued, frame i + 1 is traced while frame i is gathered.  rrt_render_multi is the blocking host-framebuffer form of
+ * Scene::draw_scene (engine.rs:186): out_fb as in rrt_render; processes that do not hold rank 0 pass NULL.
+ * RRT_MULTI_LOOPBACK (rrt_multi_create with n = 1): rank 0's own tiles travel through ncclSend/ncclRecv too -- a one-GPU test of the transport. */
+typedef struct rrt_multi rrt_multi;
+#define RRT_MULTI_LOOPBACK 1u
+int rrt_multi_create(rrt_raytracer *const *rts, uint32_t n, uint32_t frames_in_flight, uint32_t flags, rrt_multi **out);
+int rrt_dist_unique_id(void *out128);
+int rrt_dist_create(rrt_raytracer *rt, uint32_t rank, uint32_t world, const void *unique_id128, uint32_t frames_in_flight, rrt_multi **out);
+void rrt_multi_destroy(rrt_multi *g);
+int rrt_multi_enqueue(rrt_multi *g, uint32_t width, uint32_t height, void *d_fb /* device memory of rank 0's GPU; NULL elsewhere */);
+int rrt_multi_sync(rrt_multi *g);
+int rrt_render_multi(rrt_multi *g, uint32_t width, uint32_t height, uint32_t *out_fb);
+/* HIP-event time, on rank 0's stream, from "rank 0's own tiles are traced" to "frame de-tiled" of the last enqueued frame: the wait for the slowest
+ * peer + the gather + the de-tiling (-1 on processes without rank 0). */
+int rrt_multi_last_gather_ms(rrt_multi *g, double *out_ms);
+
 /* Scene::draw_scene with the reference's progressive display (engine.rs:196-253): the scene rows are traced in chunks of chunk_rows (0 = the
  * reference's 50) from y = -H/2 upward, i.e. from the BOTTOM of the canvas to the top (put_pixel, engine.rs:146-158); after each chunk its rows are
  * in out_fb (zero-initialised like Canvas::new, engine.rs:135) and on_update -- the stand-in for canvas.update(), engine.rs:253 -- is called on the

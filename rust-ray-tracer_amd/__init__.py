@@ -94,6 +94,14 @@ SYMBOLS = {
     "rrt_tiles_per_rank": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32]),
     "rrt_render_tiles_device": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P]),
     "rrt_detile_device": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32, _P, _P, _P]),
+    "rrt_multi_create": (C.c_int, [C.POINTER(_P), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
+    "rrt_dist_unique_id": (C.c_int, [_P]),
+    "rrt_dist_create": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, C.c_uint32, C.POINTER(_P)]),
+    "rrt_multi_destroy": (None, [_P]),
+    "rrt_multi_enqueue": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P]),
+    "rrt_multi_sync": (C.c_int, [_P]),
+    "rrt_render_multi": (C.c_int, [_P, C.c_uint32, C.c_uint32, _u32p]),
+    "rrt_multi_last_gather_ms": (C.c_int, [_P, _dp]),
     "rrt_render_progressive": (C.c_int, [_P, C.c_uint32, C.c_uint32, _u32p, C.c_uint32, _P, _P]),
     "rrt_get_ray_colours": (C.c_int, [_P, C.c_uint32, _dp, _dp, _u32p]),
     "rrt_intersect_rays": (C.c_int, [_P, C.c_uint32, _dp, _dp, _dp, _u8p, _dp, _dp, _dp, _u32p]),
@@ -393,6 +401,68 @@ class RayTracer:
         s = CStats()
         _check(lib().rrt_last_stats(self._h, C.byref(s)), "rrt_last_stats")
         return {n: getattr(s, n) for n, _ in CStats._fields_}
+
+
+MULTI_LOOPBACK = 1   # RRT_MULTI_LOOPBACK
+
+
+class MultiGpu:
+    """The N GPUs of one node behind one handle (include/rrt.h, rrt_multi): the screen-tile partition, the RCCL gather to rank 0 and the de-tiling
+    all happen inside the library.  MultiGpu(raytracers) = one process driving every GPU (rrt_multi_create); MultiGpu.dist(rt, rank, world, unique_id)
+    = one process per GPU (rrt_dist_create; rank 0 makes the id with MultiGpu.unique_id() and the caller broadcasts it)."""
+
+    def __init__(self, raytracers: Sequence["RayTracer"], frames_in_flight: int = 1, loopback: bool = False, _handle=None):
+        self._keep = list(raytracers)
+        if _handle is not None:
+            self._h = _handle
+            return
+        arr = (_P * len(self._keep))(*[rt._h for rt in self._keep])
+        out = _P()
+        _check(lib().rrt_multi_create(arr, len(self._keep), frames_in_flight, MULTI_LOOPBACK if loopback else 0, C.byref(out)), "rrt_multi_create")
+        self._h = out
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        _check(lib().rrt_dist_unique_id(buf), "rrt_dist_unique_id")
+        return buf.raw
+
+    @staticmethod
+    def dist(rt: "RayTracer", rank: int, world: int, unique_id: Optional[bytes], frames_in_flight: int = 1) -> "MultiGpu":
+        out = _P()
+        idbuf = C.create_string_buffer(unique_id, 128) if unique_id is not None else None
+        _check(lib().rrt_dist_create(rt._h, rank, world, idbuf, frames_in_flight, C.byref(out)), "rrt_dist_create")
+        return MultiGpu([rt], _handle=out)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.rrt_multi_destroy(h)
+
+    def render(self, width: int, height: int) -> np.ndarray:
+        """Blocking Scene::draw_scene over all GPUs, host framebuffer (rrt_render_multi)."""
+        fb = np.empty((height, width), np.uint32)
+        _check(lib().rrt_render_multi(self._h, width, height, fb.ctypes.data_as(_u32p)), "rrt_render_multi")
+        return fb
+
+    def bind_enqueue(self, fb_tensor, width: int, height: int):
+        """One ctypes call per frame: trace -> gather -> de-tile enqueued on the next slot (fb_tensor on rank 0's GPU, None elsewhere)."""
+        fn, h, w_, h_ = lib().rrt_multi_enqueue, self._h, C.c_uint32(width), C.c_uint32(height)
+        p = _P(fb_tensor.data_ptr()) if fb_tensor is not None else _P()
+
+        def enqueue():
+            rc = fn(h, w_, h_, p)
+            if rc != OK:
+                _check(rc, "rrt_multi_enqueue")
+        return enqueue
+
+    def sync(self) -> None:
+        _check(lib().rrt_multi_sync(self._h), "rrt_multi_sync")
+
+    def last_gather_ms(self) -> float:
+        v = C.c_double(-1.0)
+        _check(lib().rrt_multi_last_gather_ms(self._h, C.byref(v)), "rrt_multi_last_gather_ms")
+        return v.value
 
 
 def _stream(stream: Optional[int]) -> int:

@@ -654,6 +654,292 @@ int rrt_intersect_rays(rrt_raytracer* rt, uint32_t n, const double* origins, con
     });
 }
 
+// ------------------------------------------------------------------------------------------------ N GPUs of one node
+// The frame's 8x8-pixel tiles are dealt round-robin to the ranks (tile k -> rank k % world), every rank traces its tiles into a compact tile-major
+// buffer, ONE gather collects the buffers on rank 0 -- grouped ncclSend / ncclRecv, every peer on its own xGMI link (a ring would make the 7 hops) --
+// and rank 0 de-tiles into the row-major frame.  No exchange inside the frame.  Two hosts of the same code:
+//   rrt_multi_create   one process drives all GPUs (the Rust host: `hipSetDevice` loop + ncclCommInitAll);
+//   rrt_dist_create    one process per GPU (bench.py under torch.distributed.run): ncclCommInitRank with an id the caller broadcasts.
+// Frames are enqueued into a ring of slots, each with its own stream per GPU, tile buffer and gather buffer, so that the tracing of a frame overlaps
+// the gather and de-tiling of the one before (a rank's share of a frame is a short launch: several in flight keep the GPU full).
+// RCCL is bound at first use with dlopen: librrt_hip.so itself has no link-time dependency on it (single-GPU hosts never load it), and a process
+// that already holds an RCCL (PyTorch) shares that one.
+}  // extern "C" (reopened below)
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace {
+
+struct Rccl {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+Rccl& rccl() {
+    static Rccl R;
+    if (R.lib) return R;
+    const char* names[] = {"librccl.so.1", "librccl.so"};
+    void* h = nullptr;
+    for (const char* n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);                 // an RCCL this process already holds (PyTorch's)
+    for (const char* n : names) if (!h) h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) throw Error{RRT_ERR_UNSUPPORTED, std::string("RCCL is not available: ") + (dlerror() ? dlerror() : "dlopen failed")};
+    auto sym = [&](const char* n) { void* p = dlsym(h, n); if (!p) throw Error{RRT_ERR_UNSUPPORTED, std::string("RCCL lacks ") + n}; return p; };
+    R.GetUniqueId = (decltype(R.GetUniqueId))sym("ncclGetUniqueId"); R.CommInitRank = (decltype(R.CommInitRank))sym("ncclCommInitRank");
+    R.CommInitAll = (decltype(R.CommInitAll))sym("ncclCommInitAll"); R.CommDestroy = (decltype(R.CommDestroy))sym("ncclCommDestroy");
+    R.GroupStart = (decltype(R.GroupStart))sym("ncclGroupStart"); R.GroupEnd = (decltype(R.GroupEnd))sym("ncclGroupEnd");
+    R.Send = (decltype(R.Send))sym("ncclSend"); R.Recv = (decltype(R.Recv))sym("ncclRecv"); R.GetErrorString = (decltype(R.GetErrorString))sym("ncclGetErrorString");
+    R.lib = h;
+    return R;
+}
+#define NCCL_TRY(expr) do { ncclResult_t _r = (expr); if (_r != ncclSuccess) throw Error{RRT_ERR_HIP, std::string(#expr) + ": " + rccl().GetErrorString(_r)}; } while (0)
+
+constexpr uint32_t kMaxSlots = 8;
+
+struct Member {                      // one rank that lives in this process
+    rrt_raytracer* rt = nullptr;
+    int rank = 0;
+    ncclComm_t comm = nullptr;
+    hipStream_t stream[kMaxSlots] = {};
+    uint32_t* tiles[kMaxSlots] = {};      // this rank's tile-major buffer per slot (rank 0: a view into its gather buffer, or its own with loopback)
+    uint32_t* gathered[kMaxSlots] = {};   // rank 0 only: [world][tiles_per_rank][64]
+    hipEvent_t done[kMaxSlots] = {};      // rank 0 only: the slot's frame is de-tiled
+    hipEvent_t traced[kMaxSlots] = {};    // rank 0 only: its own tiles are traced (start of the wait for the peers)
+    uint32_t* fb = nullptr;               // rank 0 only: frame kept for the host-framebuffer entry point
+    size_t fb_bytes = 0;
+};
+
+}  // namespace
+
+struct rrt_multi {
+    std::vector<Member> members;     // ranks of this process (all of them for rrt_multi_create, one for rrt_dist_create)
+    uint32_t world = 1, depth = 1, next_slot = 0, last_slot = 0;
+    uint32_t w = 0, h = 0, tpr = 0;  // buffers are sized for this frame size
+    bool loopback = false;           // rank 0 sends its own tiles to itself through RCCL too (single-GPU test of the transport)
+    bool owns_raytracers = false;
+};
+
+namespace {
+
+void multi_free_buffers(rrt_multi* g) {
+    for (Member& m : g->members) {
+        DeviceGuard guard(m.rt->device);
+        for (uint32_t s = 0; s < kMaxSlots; s++) {
+            if (m.gathered[s]) { (void)hipFree(m.gathered[s]); if (m.rank == 0 && !g->loopback) m.tiles[s] = nullptr; m.gathered[s] = nullptr; }
+            if (m.tiles[s]) { (void)hipFree(m.tiles[s]); m.tiles[s] = nullptr; }
+        }
+    }
+    g->w = g->h = g->tpr = 0;
+}
+
+void multi_size_buffers(rrt_multi* g, uint32_t w, uint32_t h) {
+    if (g->w == w && g->h == h) return;
+    for (Member& m : g->members) { DeviceGuard guard(m.rt->device); for (uint32_t s = 0; s < g->depth; s++) HIP_TRY(hipStreamSynchronize(m.stream[s])); }
+    multi_free_buffers(g);
+    const uint32_t tpr = rrt_tiles_per_rank(w, h, g->world);
+    const size_t chunk = (size_t)tpr * 64 * sizeof(uint32_t);
+    for (Member& m : g->members) {
+        DeviceGuard guard(m.rt->device);
+        for (uint32_t s = 0; s < g->depth; s++) {
+            if (m.rank == 0) {
+                HIP_TRY(hipMalloc((void**)&m.gathered[s], chunk * g->world));
+                if (g->loopback) HIP_TRY(hipMalloc((void**)&m.tiles[s], chunk)); else m.tiles[s] = m.gathered[s];   // rank 0 traces straight into chunk 0
+            } else {
+                HIP_TRY(hipMalloc((void**)&m.tiles[s], chunk));
+            }
+        }
+    }
+    g->w = w; g->h = h; g->tpr = tpr;
+}
+
+// trace -> gather -> de-tile of one frame, enqueued on the next slot's streams; d_fb lives on rank 0's device (may be null on processes without rank 0)
+void multi_enqueue(rrt_multi* g, uint32_t w, uint32_t h, void* d_fb) {
+    multi_size_buffers(g, w, h);
+    const uint32_t s = g->next_slot; g->next_slot = (g->next_slot + 1) % g->depth;
+    const size_t count = (size_t)g->tpr * 64;
+    for (Member& m : g->members) {                                        // every stream is in order: a slot's previous frame has left its buffers by now
+        const int rc = rrt_render_tiles_device(m.rt, w, h, (uint32_t)m.rank, g->world, m.tiles[s], m.stream[s]);
+        if (rc != RRT_OK) throw Error{rc, std::string("rank ") + std::to_string(m.rank) + ": " + rrt_last_error_detail()};
+        if (m.rank == 0) { DeviceGuard guard(m.rt->device); HIP_TRY(hipEventRecord(m.traced[s], m.stream[s])); }
+    }
+    g->last_slot = s;
+    if (g->world > 1 || g->loopback) {
+        Rccl& R = rccl();
+        NCCL_TRY(R.GroupStart());
+        for (Member& m : g->members) {
+            DeviceGuard guard(m.rt->device);
+            if (m.rank == 0) {
+                for (uint32_t r = g->loopback ? 0u : 1u; r < g->world; r++) NCCL_TRY(R.Recv(m.gathered[s] + (size_t)r * count, count, ncclUint32, (int)r, m.comm, m.stream[s]));
+                if (g->loopback) NCCL_TRY(R.Send(m.tiles[s], count, ncclUint32, 0, m.comm, m.stream[s]));
+            } else {
+                NCCL_TRY(R.Send(m.tiles[s], count, ncclUint32, 0, m.comm, m.stream[s]));
+            }
+        }
+        NCCL_TRY(R.GroupEnd());
+    }
+    for (Member& m : g->members) {
+        if (m.rank != 0) continue;
+        if (!d_fb) throw Error{RRT_ERR_INVALID_ARG, "rank 0 needs a framebuffer"};
+        DeviceGuard guard(m.rt->device);
+        HIP_TRY((hipError_t)launch_detile(w, h, g->world, m.gathered[s], static_cast<uint32_t*>(d_fb), m.stream[s]));
+        HIP_TRY(hipEventRecord(m.done[s], m.stream[s]));
+    }
+}
+
+void multi_sync(rrt_multi* g) {
+    for (Member& m : g->members) { DeviceGuard guard(m.rt->device); for (uint32_t s = 0; s < g->depth; s++) HIP_TRY(hipStreamSynchronize(m.stream[s])); }
+}
+
+void multi_init_member(rrt_multi* g, Member& m) {
+    DeviceGuard guard(m.rt->device);
+    for (uint32_t s = 0; s < g->depth; s++) {
+        HIP_TRY(hipStreamCreateWithFlags(&m.stream[s], hipStreamNonBlocking));
+        if (m.rank == 0) { HIP_TRY(hipEventCreate(&m.done[s])); HIP_TRY(hipEventCreate(&m.traced[s])); }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int rrt_multi_create(rrt_raytracer* const* rts, uint32_t n, uint32_t frames_in_flight, uint32_t flags, rrt_multi** out) {
+    return guarded([&]() -> int {
+        if (!rts || !out || n == 0) throw Error{RRT_ERR_INVALID_ARG, "null argument"};
+        if (frames_in_flight == 0) frames_in_flight = 1;
+        if (frames_in_flight > kMaxSlots) throw Error{RRT_ERR_INVALID_ARG, "frames_in_flight > 8"};
+        std::vector<int> devs(n);
+        for (uint32_t i = 0; i < n; i++) {
+            if (!rts[i]) throw Error{RRT_ERR_INVALID_ARG, "null raytracer"};
+            devs[i] = rts[i]->device;
+            for (uint32_t j = 0; j < i; j++) if (devs[j] == devs[i]) throw Error{RRT_ERR_INVALID_ARG, "two raytracers on one device (RCCL wants one rank per GPU)"};
+        }
+        std::unique_ptr<rrt_multi, void (*)(rrt_multi*)> g(new rrt_multi, rrt_multi_destroy);
+        g->world = n; g->depth = frames_in_flight; g->loopback = (flags & RRT_MULTI_LOOPBACK) != 0;
+        g->members.resize(n);
+        for (uint32_t i = 0; i < n; i++) { g->members[i].rt = rts[i]; g->members[i].rank = (int)i; }
+        if (n > 1 || g->loopback) {
+            std::vector<ncclComm_t> comms(n);
+            NCCL_TRY(rccl().CommInitAll(comms.data(), (int)n, devs.data()));
+            for (uint32_t i = 0; i < n; i++) g->members[i].comm = comms[i];
+        }
+        for (Member& m : g->members) multi_init_member(g.get(), m);
+        *out = g.release();
+        return RRT_OK;
+    });
+}
+
+int rrt_dist_unique_id(void* out128) {
+    return guarded([&]() -> int {
+        if (!out128) throw Error{RRT_ERR_INVALID_ARG, "null argument"};
+        ncclUniqueId id;
+        NCCL_TRY(rccl().GetUniqueId(&id));
+        std::memcpy(out128, id.internal, NCCL_UNIQUE_ID_BYTES);
+        return RRT_OK;
+    });
+}
+
+int rrt_dist_create(rrt_raytracer* rt, uint32_t rank, uint32_t world, const void* unique_id128, uint32_t frames_in_flight, rrt_multi** out) {
+    return guarded([&]() -> int {
+        if (!rt || !out || world == 0 || rank >= world || (world > 1 && !unique_id128)) throw Error{RRT_ERR_INVALID_ARG, "bad argument"};
+        if (frames_in_flight == 0) frames_in_flight = 1;
+        if (frames_in_flight > kMaxSlots) throw Error{RRT_ERR_INVALID_ARG, "frames_in_flight > 8"};
+        std::unique_ptr<rrt_multi, void (*)(rrt_multi*)> g(new rrt_multi, rrt_multi_destroy);
+        g->world = world; g->depth = frames_in_flight;
+        g->members.resize(1);
+        g->members[0].rt = rt; g->members[0].rank = (int)rank;
+        if (world > 1) {
+            DeviceGuard guard(rt->device);
+            ncclUniqueId id;
+            std::memcpy(id.internal, unique_id128, NCCL_UNIQUE_ID_BYTES);
+            NCCL_TRY(rccl().CommInitRank(&g->members[0].comm, (int)world, id, (int)rank));
+        }
+        multi_init_member(g.get(), g->members[0]);
+        *out = g.release();
+        return RRT_OK;
+    });
+}
+
+void rrt_multi_destroy(rrt_multi* g) {
+    if (!g) return;
+    try {
+        for (Member& m : g->members) { if (!m.rt) continue; DeviceGuard guard(m.rt->device); for (uint32_t s = 0; s < kMaxSlots; s++) if (m.stream[s]) (void)hipStreamSynchronize(m.stream[s]); }
+        multi_free_buffers(g);
+        for (Member& m : g->members) {
+            if (!m.rt) continue;
+            DeviceGuard guard(m.rt->device);
+            if (m.comm) (void)rccl().CommDestroy(m.comm);
+            for (uint32_t s = 0; s < kMaxSlots; s++) { if (m.stream[s]) (void)hipStreamDestroy(m.stream[s]); if (m.done[s]) (void)hipEventDestroy(m.done[s]); if (m.traced[s]) (void)hipEventDestroy(m.traced[s]); }
+            if (m.fb) (void)hipFree(m.fb);
+        }
+    } catch (...) {}
+    delete g;
+}
+
+int rrt_multi_enqueue(rrt_multi* g, uint32_t width, uint32_t height, void* d_fb) {
+    return guarded([&]() -> int {
+        if (!g) throw Error{RRT_ERR_INVALID_ARG, "null handle"};
+        check_frame(g->members[0].rt, width, height);
+        multi_enqueue(g, width, height, d_fb);
+        return RRT_OK;
+    });
+}
+
+int rrt_multi_sync(rrt_multi* g) {
+    return guarded([&]() -> int {
+        if (!g) throw Error{RRT_ERR_INVALID_ARG, "null handle"};
+        multi_sync(g);
+        return RRT_OK;
+    });
+}
+
+int rrt_multi_last_gather_ms(rrt_multi* g, double* out_ms) {
+    return guarded([&]() -> int {
+        if (!g || !out_ms) throw Error{RRT_ERR_INVALID_ARG, "null argument"};
+        *out_ms = -1.0;
+        for (Member& m : g->members) {
+            if (m.rank != 0) continue;
+            DeviceGuard guard(m.rt->device);
+            HIP_TRY(hipEventSynchronize(m.done[g->last_slot]));
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, m.traced[g->last_slot], m.done[g->last_slot]));
+            *out_ms = ms;
+        }
+        return RRT_OK;
+    });
+}
+
+int rrt_render_multi(rrt_multi* g, uint32_t width, uint32_t height, uint32_t* out_fb) {
+    return guarded([&]() -> int {
+        if (!g) throw Error{RRT_ERR_INVALID_ARG, "null handle"};
+        check_frame(g->members[0].rt, width, height);
+        Member* root = nullptr;
+        for (Member& m : g->members) if (m.rank == 0) root = &m;
+        const size_t bytes = sizeof(uint32_t) * (size_t)width * height;
+        if (root) {
+            if (!out_fb) throw Error{RRT_ERR_INVALID_ARG, "null framebuffer"};
+            DeviceGuard guard(root->rt->device);
+            if (root->fb_bytes < bytes) { if (root->fb) (void)hipFree(root->fb); root->fb = nullptr; root->fb_bytes = 0; HIP_TRY(hipMalloc((void**)&root->fb, bytes)); root->fb_bytes = bytes; }
+        }
+        const uint32_t slot = g->next_slot;
+        multi_enqueue(g, width, height, root ? root->fb : nullptr);
+        if (root) {
+            DeviceGuard guard(root->rt->device);
+            HIP_TRY(hipMemcpyAsync(out_fb, root->fb, bytes, hipMemcpyDeviceToHost, root->stream[slot]));   // pinned (rrt_host_buffer_register) or pageable destination
+        }
+        multi_sync(g);                                                    // blocking: the frame is in out_fb on return
+        return RRT_OK;
+    });
+}
+
 #ifdef RRT_PROFILE
 // developer build only: read and clear the 16 work counters
 int rrt_prof_counters(rrt_raytracer* rt, unsigned long long* out16) {

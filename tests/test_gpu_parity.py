@@ -177,6 +177,30 @@ def test_tile_partition_reassembles_frame(rrt, teapot_rt):
     assert np.array_equal(fb.cpu().numpy().view(np.uint32), full)
 
 
+def test_render_multi_world1_through_rccl(rrt, teapot, teapot_rt):
+    """rrt_render_multi / rrt_multi_enqueue (the N-GPU frame behind ONE C call: tile partition, RCCL gather, de-tiling inside the library) with the one
+    GPU of this box.  Loopback makes rank 0's own tiles travel through ncclSend/ncclRecv (ncclCommInitAll over one device), so the RCCL binding
+    (dlopen), the grouped point-to-point gather, the slot ring and the de-tiling all run; the frame must equal the single-launch frame bit for bit,
+    at an odd size too, with frames in flight, and through the one-process-per-GPU form (rrt_dist_create, world 1)."""
+    torch = pytest.importorskip("torch")
+    rt = rrt.RayTracer(teapot, rrt.default_lights())
+    for (w, h) in ((203, 117), (640, 480)):
+        full = teapot_rt.render(w, h)
+        for loopback in (False, True):
+            mg = rrt.MultiGpu([rt], frames_in_flight=3, loopback=loopback)
+            assert np.array_equal(mg.render(w, h), full), (w, h, loopback)
+            fbs = [torch.zeros((h, w), dtype=torch.int32, device="cuda") for _ in range(5)]
+            for fb in fbs:                                                     # five frames through a ring of three slots
+                mg.bind_enqueue(fb, w, h)()
+            mg.sync()
+            for fb in fbs:
+                assert np.array_equal(fb.cpu().numpy().view(np.uint32), full), (w, h, loopback)
+            del mg
+    dg = rrt.MultiGpu.dist(rt, 0, 1, None, frames_in_flight=2)
+    assert np.array_equal(dg.render(203, 117), teapot_rt.render(203, 117))
+    assert len(rrt.MultiGpu.unique_id()) == 128
+
+
 def test_full_size_properties_1080p(teapot_rt, teapot_oracle):
     """configs[1] (model2.obj @1920x1080) is too slow to check pixel by pixel on the CPU in a test, so: (a) a 1080p frame is deterministic,
     (b) random 16-row bands of it equal the oracle's rows (the oracle renders a row independently of the frame), (c) frame invariants."""
@@ -431,7 +455,10 @@ def test_bench_multi_gpu_choreography_single_rank():
         assert len(lines) == 1, r.stdout
         return json.loads(lines[0])
     single = run({})
-    piped = run({"RRT_BENCH_FORCE_DIST": "1"})
-    plain = run({"RRT_BENCH_FORCE_DIST": "1"}, "--pipeline-depth", "0")
-    assert single["frame_checksum"] == piped["frame_checksum"] == plain["frame_checksum"]
+    inlib = run({"RRT_BENCH_FORCE_DIST": "1"})                                            # default: the library's own gather (rrt_dist_create / rrt_multi_enqueue)
+    piped = run({"RRT_BENCH_FORCE_DIST": "1"}, "--gather", "torch")
+    plain = run({"RRT_BENCH_FORCE_DIST": "1"}, "--gather", "torch", "--pipeline-depth", "0")
+    assert single["frame_checksum"] == inlib["frame_checksum"] == piped["frame_checksum"] == plain["frame_checksum"]
     assert single["n_gpus"] == 1 and single["unit"] == "Mrays/s"
+    assert inlib["gather"] == "lib" and piped["gather"] == "torch" and inlib["pipeline_fallback"] is False and inlib["gather_ms"] is not None
+    assert "frame_ms_host_fb" in single and single["host_fb"]["identical_to_device_frame"] and "setup_ms" in single
