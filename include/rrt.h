@@ -191,8 +191,9 @@ int rrt_intersect_rays(rrt_raytracer *rt, uint32_t n, const double *origins, con
 int rrt_last_stats(const rrt_raytracer *rt, rrt_stats *out);
 /* Wall time of the set-up stages that run once per scene (the reference does all of them inside parse_obj_file_lines, utils.rs:139-213,
  * before its one frame): model side = file read, .obj/.mtl parse, texture decode, octree build (octree.rs:41-241); raytracer side =
- * own-list index build (clusters.cpp) and upload to HBM.  Either handle may be NULL (its fields stay 0). */
-typedef struct { double read_ms, parse_ms, texture_ms, octree_ms, index_ms, upload_ms; } rrt_setup_times;
+ * own-list index build (clusters.cpp) and upload to HBM; hip_init_ms = bringing the device's HIP context up at the start of rrt_raytracer_create
+ * (a one-off of the process, near 0 for every later raytracer).  Either handle may be NULL (its fields stay 0). */
+typedef struct { double read_ms, parse_ms, texture_ms, octree_ms, index_ms, upload_ms, hip_init_ms; } rrt_setup_times;
 int rrt_get_setup_times(const rrt_model *m, const rrt_raytracer *rt, rrt_setup_times *out);
 int rrt_device_count(int *count);
 const char *rrt_strerror(int status);

@@ -68,7 +68,7 @@ class CStats(C.Structure):
 
 
 class CSetupTimes(C.Structure):
-    _fields_ = [(n, C.c_double) for n in ("read_ms", "parse_ms", "texture_ms", "octree_ms", "index_ms", "upload_ms")]
+    _fields_ = [(n, C.c_double) for n in ("read_ms", "parse_ms", "texture_ms", "octree_ms", "index_ms", "upload_ms", "hip_init_ms")]
 
 
 # every symbol include/rrt.h declares: (restype, argtypes)

@@ -5,13 +5,17 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <new>
+#include <thread>
 
 #include "device_scene.hpp"
 #include "model.hpp"
+#include "parallel.hpp"
 
 struct rrt_model { rrt::Model m; };
 
@@ -20,6 +24,7 @@ struct rrt_raytracer {
     rrt::DevScene scene{};
     rrt_options opt{};
     std::vector<void*> allocs;       // every hipMalloc of this raytracer
+    void* arena = nullptr; size_t arena_bytes = 0, arena_used = 0;   // the scene's buffers (one allocation)
     uint64_t scene_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     rrt_stats stats{};
@@ -29,7 +34,7 @@ struct rrt_raytracer {
     void* host_fb = nullptr;         // device framebuffer kept between rrt_render calls (host-buffer entry point)
     size_t host_fb_bytes = 0;
     uint32_t n_suspects = 0;         // triangles whose plane contains the origin (exactness guard, clusters.cpp)
-    double index_ms = 0, upload_ms = 0;  // set-up stages of rrt_raytracer_create
+    double index_ms = 0, upload_ms = 0, hip_init_ms = 0;  // set-up stages of rrt_raytracer_create
     hipStream_t own_stream = nullptr;   // rrt_render's stream (non-blocking: independent of the legacy default stream)
     void* staging = nullptr;         // pinned host staging for callers whose framebuffer is pageable memory
     size_t staging_bytes = 0;
@@ -65,6 +70,32 @@ template <class F> int guarded(F&& f) {
     catch (...) { set_error_detail("unknown failure"); return RRT_ERR_INVALID_ARG; }
 }
 
+// The HIP context and this library's code object come up lazily, at the first HIP call that needs them (~90 ms on a fresh process).  A model is
+// always loaded before a raytracer is created, so the loaders start that work on a helper thread and rrt_raytracer_create finds it done.
+struct DeviceWarmer {
+    std::thread th; std::once_flag once; std::mutex mu; bool joined = false;
+    void start() {
+        std::call_once(once, [this] {
+            th = std::thread([] {
+                int n = 0;
+                if (hipGetDeviceCount(&n) != hipSuccess || n == 0) { (void)hipGetLastError(); return; }
+                if (hipFree(nullptr) == hipSuccess) {
+                    void* p = nullptr; char probe[256] = {};
+                    if (hipMalloc(&p, 1 << 20) == hipSuccess) {           // the first allocation and the first host-to-device copy of a process set up the
+                        (void)hipMemcpy(p, probe, sizeof probe, hipMemcpyHostToDevice);   // runtime's memory pools and staging buffers (~80 ms), whoever issues them
+                        (void)hipFree(p);
+                    }
+                    preload_kernels();
+                }
+                (void)hipGetLastError();
+            });
+        });
+    }
+    void join() { std::lock_guard<std::mutex> lk(mu); if (!joined && th.joinable()) th.join(); joined = true; }
+    ~DeviceWarmer() { join(); }
+};
+DeviceWarmer g_warmer;
+
 Box default_root(const double* root) {
     Box b;
     if (root) { b.lo[0] = root[0]; b.hi[0] = root[1]; b.lo[1] = root[2]; b.hi[1] = root[3]; b.lo[2] = root[4]; b.hi[2] = root[5]; }
@@ -89,12 +120,14 @@ void validate_model(const Model& m) {
     for (auto& t : m.triangles) if (t.mat >= m.materials.size()) throw Error{RRT_ERR_INVALID_ARG, "triangle material index out of range"};
 }
 
+// Scene buffers are carved out of ONE device allocation (a hipMalloc per buffer costs milliseconds each: 15 of them were most of the teapot's
+// upload time); a buffer that does not fit the arena's estimate gets an allocation of its own.
 template <class T> T* upload(rrt_raytracer* rt, const T* host, size_t count) {
     void* d = nullptr;
-    const size_t bytes = sizeof(T) * (count ? count : 1);
-    HIP_TRY(hipMalloc(&d, bytes));
-    rt->allocs.push_back(d);
-    if (count) HIP_TRY(hipMemcpy(d, host, sizeof(T) * count, hipMemcpyHostToDevice));
+    const size_t bytes = sizeof(T) * (count ? count : 1), padded = (bytes + 255) & ~(size_t)255;
+    if (rt->arena && rt->arena_used + padded <= rt->arena_bytes) { d = static_cast<char*>(rt->arena) + rt->arena_used; rt->arena_used += padded; }
+    else { HIP_TRY(hipMalloc(&d, bytes)); rt->allocs.push_back(d); }
+    if (count) HIP_TRY(hipMemcpyAsync(d, host, sizeof(T) * count, hipMemcpyHostToDevice, nullptr));   // (host buffers outlive the hipDeviceSynchronize that ends the upload)
     rt->scene_bytes += sizeof(T) * count;
     return static_cast<T*>(d);
 }
@@ -207,6 +240,7 @@ int rrt_device_count(int* count) {
 int rrt_model_load_obj(const char* obj_path, const double* root, rrt_model** out) {
     return guarded([&]() -> int {
         if (!obj_path || !out) throw Error{RRT_ERR_INVALID_ARG, "null argument"};
+        g_warmer.start();
         auto m = std::make_unique<rrt_model>();
         load_obj(obj_path, default_root(root), m->m);
         validate_model(m->m);
@@ -220,6 +254,7 @@ int rrt_model_from_arrays(uint32_t n_tris, const double* pos, const double* uv, 
                           const double* root, rrt_model** out) {
     return guarded([&]() -> int {
         if (!out || (n_tris && (!pos || !uv || !nrm || !mat)) || (n_mats && !mats) || (n_tex && !tex)) throw Error{RRT_ERR_INVALID_ARG, "null argument"};
+        g_warmer.start();
         auto m = std::make_unique<rrt_model>();
         Model& M = m->m;
         M.root = default_root(root);
@@ -335,12 +370,17 @@ int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n
         rrt_options o;
         if (opt) o = *opt; else { o.surface_offset = 0.0001; o.max_reflection_depth = 5; o.flags = 0; o.vp_w = o.vp_h = o.vp_d = 1.0; }
         if (o.max_reflection_depth > RRT_MAX_REFLECT) throw Error{RRT_ERR_INVALID_ARG, "max_reflection_depth > 8"};
+        g_warmer.join();
         int n_dev = 0;
         if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) { (void)hipGetLastError(); throw Error{RRT_ERR_NO_DEVICE, "no HIP device visible"}; }
         if (device < 0 || device >= n_dev) throw Error{RRT_ERR_NO_DEVICE, "device index out of range"};
+        const auto t_init0 = std::chrono::steady_clock::now();
         DeviceGuard guard(device);
+        HIP_TRY(hipFree(nullptr));                                          // brings the HIP context of this device up (a one-off of the process: ~90 ms on a fresh one)
+        const double hip_init_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_init0).count();
 
         std::unique_ptr<rrt_raytracer, void (*)(rrt_raytracer*)> rt(new rrt_raytracer, rrt_raytracer_destroy);
+        rt->hip_init_ms = hip_init_ms;
         rt->device = device; rt->opt = o;
         const Model& M = m->m; const FlatOctree& T = M.tree;
         const size_t n_nodes = T.box.size(), n_slots = T.own_idx.size();   // n_slots: every triangle in the tree appears in exactly one own list
@@ -350,8 +390,10 @@ int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n
         ClusterSet CS;
         build_clusters(M, !(o.flags & RRT_FLAG_NO_CULL), CS);
         const size_t n_slots_c = CS.slot_tri.size();
-        std::vector<DevNode> nodes(n_nodes);
-        for (size_t i = 0; i < n_nodes; i++) {
+        // (plain arrays: a std::vector would zero 250 MB on one thread before the workers fill it)
+        std::unique_ptr<DevNode[]> nodes(new DevNode[n_nodes ? n_nodes : 1]);
+        parallel_ranges(n_nodes, 1 << 14, [&](size_t nb, size_t ne, size_t) {
+        for (size_t i = nb; i < ne; i++) {
             DevNode& d = nodes[i];
             for (int k = 0; k < 3; k++) {
                 d.lo[k] = T.box[i].lo[k]; d.hi[k] = T.box[i].hi[k];
@@ -367,8 +409,10 @@ int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n
                 if (CS.node_leaf_slot[d.first_child + k] != kPadSlot) { d.flags |= 1u << (9 + k); d.leaf_base = CS.node_leaf_slot[d.first_child + k]; }   // ends at the first one
             }
         }
-        std::vector<DevTriGeom> geom(n_slots_c); std::vector<DevTriAttr> attr(n_slots_c);
-        for (size_t s = 0; s < n_slots_c; s++) {
+        });
+        std::unique_ptr<DevTriGeom[]> geom(new DevTriGeom[n_slots_c ? n_slots_c : 1]); std::unique_ptr<DevTriAttr[]> attr(new DevTriAttr[n_slots_c ? n_slots_c : 1]);
+        parallel_ranges(n_slots_c, 1 << 14, [&](size_t sb, size_t se, size_t) {
+        for (size_t s = sb; s < se; s++) {
             if (CS.slot_tri[s] == kPadSlot) { std::memset(&geom[s], 0, sizeof(DevTriGeom)); std::memset(&attr[s], 0, sizeof(DevTriAttr)); attr[s].orig = kPadSlot; continue; }
             const Triangle& t = M.triangles[CS.slot_tri[s]];
             DevTriGeom& g = geom[s];
@@ -382,7 +426,21 @@ int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n
             a.nrm[6] = t.n3.x; a.nrm[7] = t.n3.y; a.nrm[8] = t.n3.z;
             a.mat = t.mat; a.orig = CS.slot_tri[s];
         }
+        });
         const auto t_index1 = clk::now();
+        {
+            size_t need = (size_t)1 << 20;
+            for (auto& t : M.textures) need += t.rgb.size() + 256;
+            need += n_nodes * sizeof(DevNode) + n_slots_c * (sizeof(DevTriGeom) + sizeof(DevTriAttr)) + 4096;
+            need += (CS.supers.size() + CS.cboxes.size() + CS.child_boxes.size() + CS.tboxes.size()) * 32 + 4096;
+            need += M.materials.size() * sizeof(DevMaterial) + M.textures.size() * sizeof(DevTexture) + (RRT_MAX_SUSPECTS + 1) * sizeof(DevSuspect);
+            HIP_TRY(hipMalloc(&rt->arena, need));
+            rt->allocs.push_back(rt->arena);
+            rt->arena_bytes = need;
+        }
+        const bool trace = std::getenv("RRT_SETUP_TRACE") != nullptr;
+        auto lap = [&, last = t_index1](const char* what) mutable { if (trace) { const auto n = clk::now(); fprintf(stderr, "[setup] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(n - last).count()); last = n; } };
+        lap("arena hipMalloc");
         std::vector<DevTexture> texs(M.textures.size());
         for (size_t i = 0; i < texs.size(); i++) {
             texs[i].rgb = upload(rt.get(), M.textures[i].rgb.data(), M.textures[i].rgb.size());
@@ -395,9 +453,10 @@ int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n
             d.ks[0] = s.ks.x; d.ks[1] = s.ks.y; d.ks[2] = s.ks.z; d.ns = s.ns; d.kr = s.kr; d.tex = s.tex; d.bump = s.bump;
             d.tex_desc = texs[s.tex]; d.bump_desc = s.bump >= 0 ? texs[s.bump] : DevTexture{nullptr, 0, 0};
         }
+        lap("textures enqueued");
         DevScene& S = rt->scene;
-        S.nodes = upload(rt.get(), nodes.data(), nodes.size());
-        S.geom = upload(rt.get(), geom.data(), geom.size());
+        S.nodes = upload(rt.get(), nodes.get(), n_nodes);
+        S.geom = upload(rt.get(), geom.get(), n_slots_c);
         S.supers = upload(rt.get(), CS.supers.data(), CS.supers.size());
         S.cboxes = upload(rt.get(), CS.cboxes.data(), CS.cboxes.size());
         S.child_boxes = upload(rt.get(), CS.child_boxes.data(), CS.child_boxes.size());
@@ -405,13 +464,15 @@ int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n
         S.cull_enabled = (o.flags & RRT_FLAG_NO_CULL) ? 0u : 1u;
         S.has_groups = CS.has_groups ? 1u : 0u;
         S.bounds_plain = 1u;
-        for (const DevNode& d : nodes)
+        for (size_t i = 0; i < n_nodes; i++) { const DevNode& d = nodes[i];
             for (int k = 0; k < 3; k++)
                 for (double v : {d.lo[k], d.mid[k], d.hi[k]})
                     if (!(v == 0.0 || (std::fabs(v) > 0x1p-200 && std::fabs(v) < 0x1p200))) S.bounds_plain = 0u;
+        }
         S.cull_limit = (float)(CS.scene_magnitude * 4.0);
+        lap("geometry + index enqueued");
+        std::vector<DevSuspect> sus;                                      // (lives until the hipDeviceSynchronize below: uploads are asynchronous)
         {   // exactness guard of the index for rays from `origin` (clusters.cpp, find_origin_suspects)
-            std::vector<DevSuspect> sus;
             const double org[3] = {origin.x, origin.y, origin.z};
             if (S.cull_enabled) find_origin_suspects(M, org, CS.pad, sus);
             rt->n_suspects = (uint32_t)sus.size();
@@ -419,7 +480,7 @@ int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n
             if (sus.size() > RRT_MAX_SUSPECTS) sus.resize(1);              // beyond the cap every ray from the origin runs unfiltered; the list is not read
             S.suspects = upload(rt.get(), sus.data(), sus.size());
         }
-        S.attr = upload(rt.get(), attr.data(), attr.size());
+        S.attr = upload(rt.get(), attr.get(), n_slots_c);
         S.mats = upload(rt.get(), mats.data(), mats.size());
         S.tex = upload(rt.get(), texs.data(), texs.size());
         S.n_nodes = (uint32_t)n_nodes; S.n_slots = (uint32_t)n_slots; S.n_mats = (uint32_t)mats.size(); S.n_tex = (uint32_t)texs.size();
@@ -434,8 +495,11 @@ int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n
         { void* pb = nullptr; HIP_TRY(hipMalloc(&pb, 24 * sizeof(unsigned long long))); HIP_TRY(hipMemset(pb, 0, 24 * sizeof(unsigned long long)));
           rt->allocs.push_back(pb); S.prof = static_cast<unsigned long long*>(pb); }
 #endif
+        lap("suspects, attr, materials");
         HIP_TRY(hipEventCreate(&rt->ev0)); HIP_TRY(hipEventCreate(&rt->ev1));
+        lap("hipEventCreate x2");
         HIP_TRY(hipDeviceSynchronize());
+        lap("hipDeviceSynchronize");
         rt->index_ms = std::chrono::duration<double, std::milli>(t_index1 - t_index0).count();
         rt->upload_ms = std::chrono::duration<double, std::milli>(clk::now() - t_index1).count();
         // Own-list filter variant: forced by a flag, else measured on the first frame of each frame size (tune_variant below)
@@ -958,7 +1022,7 @@ int rrt_get_setup_times(const rrt_model* m, const rrt_raytracer* rt, rrt_setup_t
         if (!out) throw Error{RRT_ERR_INVALID_ARG, "null argument"};
         std::memset(out, 0, sizeof *out);
         if (m) { out->read_ms = m->m.read_ms; out->parse_ms = m->m.parse_ms; out->texture_ms = m->m.texture_ms; out->octree_ms = m->m.octree_ms; }
-        if (rt) { out->index_ms = rt->index_ms; out->upload_ms = rt->upload_ms; }
+        if (rt) { out->index_ms = rt->index_ms; out->upload_ms = rt->upload_ms; out->hip_init_ms = rt->hip_init_ms; }
         return RRT_OK;
     });
 }

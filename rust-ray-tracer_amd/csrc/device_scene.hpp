@@ -105,6 +105,7 @@ int launch_ray_colours(const DevScene& s, uint32_t n, const double* d_origins, c
 int launch_intersect(const DevScene& s, uint32_t n, const double* d_origins, const double* d_dirs, const double* d_max_t,
                      uint8_t* d_hit, double* d_t, double* d_u, double* d_v, uint32_t* d_tri, void* stream, bool bundle);
 uint32_t stack_bytes_per_wave(uint32_t levels);
+void preload_kernels();
 
 }  // namespace rrt
 

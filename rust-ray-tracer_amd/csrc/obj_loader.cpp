@@ -2,6 +2,8 @@
 // Same directive set, same defaults and the same failure points; a reference `expect`/`unwrap`/`assert!` panic
 // becomes rrt::Error{RRT_ERR_PARSE|RRT_ERR_IO} carried back over the C ABI as a status code.
 #include <charconv>
+#include <cstdio>
+#include <cstdlib>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -10,7 +12,13 @@
 #include <sstream>
 #include <string_view>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include "model.hpp"
+#include "parallel.hpp"
 
 namespace rrt {
 namespace {
@@ -101,17 +109,31 @@ struct Loader {
     std::unordered_map<std::string, uint32_t> material_by_name;   // MaterialMap.materials, material.rs:25-28
     std::vector<Vec3> v, vt, vn;                                  // SceneData.vertices / vertex_texture_coords / vertex_normal_coords
 
-    uint32_t load_texture(const std::string& name) {   // get_texture_from_file_name, utils.rs:345-368
-        std::vector<uint8_t> bytes; uint32_t w = 0, h = 0, ch = 0;
-        const auto t0 = std::chrono::steady_clock::now();
-        decode_image_file(dir + name, bytes, w, h, ch);
-        m.texture_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        // utils.rs:353 walks `as_bytes().chunks(3)` whatever the colour type; only a 3-byte-per-pixel buffer gives
-        // width*height colours, anything else indexes out of bounds later (raytracer.rs:55).  Refuse it here.
-        if (ch != 3) fail(RRT_ERR_UNSUPPORTED, "texture '" + name + "' is not 3 bytes per pixel");
-        Texture t; t.rgb = std::move(bytes); t.width = w; t.height = h;
-        m.textures.push_back(std::move(t));
+    // get_texture_from_file_name, utils.rs:345-368.  The reference decodes a texture where its "map_Ka"/"bump" line stands; here the line only
+    // reserves the texture's index and the files of one .mtl are decoded together afterwards, one worker per file (six 1024x1024 JPEGs are
+    // most of the teapot's set-up time).  A decode failure is still reported in line order: before any later failure of the .mtl text.
+    std::vector<std::pair<uint32_t, std::string>> pending_textures;
+    uint32_t load_texture(const std::string& name) {
+        m.textures.emplace_back();
+        pending_textures.emplace_back((uint32_t)m.textures.size() - 1, name);
         return (uint32_t)m.textures.size() - 1;
+    }
+    void decode_pending_textures() {
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<std::pair<uint32_t, std::string>> work;
+        work.swap(pending_textures);
+        parallel_ranges(work.size(), 1, [&](size_t b, size_t e, size_t) {
+            for (size_t i = b; i < e; i++) {
+                std::vector<uint8_t> bytes; uint32_t w = 0, h = 0, ch = 0;
+                decode_image_file(dir + work[i].second, bytes, w, h, ch);
+                // utils.rs:353 walks `as_bytes().chunks(3)` whatever the colour type; only a 3-byte-per-pixel buffer gives
+                // width*height colours, anything else indexes out of bounds later (raytracer.rs:55).  Refuse it here.
+                if (ch != 3) fail(RRT_ERR_UNSUPPORTED, "texture '" + work[i].second + "' is not 3 bytes per pixel");
+                Texture& t = m.textures[work[i].first];
+                t.rgb = std::move(bytes); t.width = w; t.height = h;
+            }
+        });
+        m.texture_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
 
     void parse_mtl(const std::string& text) {   // parse_mtl_file_lines, utils.rs:22-137
@@ -163,8 +185,14 @@ struct Loader {
                 kr = r;
             }
         };
-        for_each_line(text, on_line);
-        on_line("END");                                                 // utils.rs:44-45
+        try {
+            for_each_line(text, on_line);
+            on_line("END");                                             // utils.rs:44-45
+        } catch (const Error&) {
+            decode_pending_textures();                                  // a texture named before the failing line fails first, as in the reference
+            throw;
+        }
+        decode_pending_textures();
     }
 
     // get_vertex_attributes, utils.rs:236-251: "i", "i/t" or "i/t/n"
@@ -208,31 +236,154 @@ struct Loader {
         return tri;
     }
 
-    void parse_obj(const std::string& text) {   // parse_obj_file_lines, utils.rs:139-213
-        std::optional<uint32_t> current_material;
-        for_each_line(text, [&](sv line) {
+    // parse_obj_file_lines, utils.rs:139-213, in two phases so that a 250 MB soup parses on every host core:
+    //  (1) the text is cut at line ends into one chunk per worker; each chunk is tokenised on its own: "v"/"vt"/"vn" values, "f" index
+    //      triples with the number of v/vt/vn lines the CHUNK had seen before them, and the rare directives ("mtllib", "usemtl") and
+    //      parse failures as `specials` in line order;
+    //  (2) the chunks are walked in file order (directives take effect exactly where they stand: utils.rs:168-187), the faces are resolved
+    //      in parallel against the v/vt/vn counts of THEIR line (a face sees only what the reference had parsed by then: utils.rs:272-329),
+    //      and the earliest failure in file order is the one reported, as the reference's first panic would be.
+    struct FaceRec { uint64_t vi[3], ti[3], ni[3]; uint32_t nv, nvt, nvn; uint8_t has_t, has_n, bad_k; uint32_t bad_msg; };
+    struct Special { enum Kind { kMtllib, kUsemtl, kError } kind; size_t face_pos; std::string arg; int status; };
+    struct Chunk { std::vector<Vec3> v, vt, vn; std::vector<FaceRec> faces; std::vector<Special> specials; std::vector<std::string> msgs; };
+
+    static void parse_chunk(sv text, Chunk& C) {
+        size_t i = 0;
+        while (i < text.size()) {
+            size_t j = text.find('\n', i);
+            if (j == sv::npos) j = text.size();
+            sv line = text.substr(i, j - i);
+            if (!line.empty() && line.back() == '\r') line.remove_suffix(1);
+            i = j + 1;
             Tokens t{line};
             auto type = t.next();
-            if (!type) return;
-            if (*type == "mtllib") {                                    // utils.rs:168-175
-                auto nm = t.next();
-                if (!nm) fail(RRT_ERR_PARSE, "Invalid .mtl file name");
-                parse_mtl(read_file(dir + std::string(*nm)));
-            } else if (*type == "usemtl") {                             // utils.rs:176-187
-                auto nm = t.next();
-                if (!nm) fail(RRT_ERR_PARSE, "Invalid material name");
-                auto it = material_by_name.find(std::string(*nm));
-                if (it == material_by_name.end()) fail(RRT_ERR_PARSE, "Material not found, is it in your mtl file?");
-                current_material = it->second;
-            } else if (*type == "v") { v.push_back(get_vertex(t));      // utils.rs:188-191
-            } else if (*type == "vt") { vt.push_back(get_vertex(t));    // utils.rs:199-202
-            } else if (*type == "vn") { vn.push_back(get_vertex(t));    // utils.rs:203-206
-            } else if (*type == "f") {                                  // utils.rs:192-198
-                if (!current_material) fail(RRT_ERR_PARSE, "face before any usemtl");
-                m.triangles.push_back(get_triangle(t, *current_material));
+            if (!type) continue;
+            try {
+                if (*type == "v") C.v.push_back(get_vertex(t));                 // utils.rs:188-191
+                else if (*type == "vt") C.vt.push_back(get_vertex(t));          // utils.rs:199-202
+                else if (*type == "vn") C.vn.push_back(get_vertex(t));          // utils.rs:203-206
+                else if (*type == "f") {                                        // utils.rs:192-198, 253-343
+                    FaceRec f{}; f.bad_k = 3; f.nv = (uint32_t)C.v.size(); f.nvt = (uint32_t)C.vt.size(); f.nvn = (uint32_t)C.vn.size();
+                    sv toks[3];
+                    for (int k = 0; k < 3; k++) {
+                        auto tok = t.next();
+                        if (!tok) fail(RRT_ERR_PARSE, "No data for vertex " + std::to_string(k + 1));
+                        toks[k] = *tok;
+                    }
+                    for (int k = 0; k < 3 && f.bad_k == 3; k++) {
+                        try {
+                            std::optional<uint64_t> ti, ni;
+                            vertex_attributes(toks[k], f.vi[k], ti, ni);
+                            if (ti) { f.ti[k] = *ti; f.has_t |= (uint8_t)(1u << k); }
+                            if (ni) { f.ni[k] = *ni; f.has_n |= (uint8_t)(1u << k); }
+                        } catch (const Error& e) {                               // reported only if no earlier vertex of this face fails its range check first
+                            f.bad_k = (uint8_t)k; f.bad_msg = (uint32_t)C.msgs.size(); C.msgs.push_back(e.detail);
+                        }
+                    }
+                    C.faces.push_back(f);
+                } else if (*type == "mtllib" || *type == "usemtl") {
+                    auto nm = t.next();
+                    if (!nm) fail(RRT_ERR_PARSE, *type == "mtllib" ? "Invalid .mtl file name" : "Invalid material name");
+                    C.specials.push_back(Special{*type == "mtllib" ? Special::kMtllib : Special::kUsemtl, C.faces.size(), std::string(*nm), 0});
+                }
+            } catch (const Error& e) {
+                C.specials.push_back(Special{Special::kError, C.faces.size(), e.detail, e.status});
+                return;                                                         // nothing after the reference's first panic matters
+            }
+        }
+    }
+
+    void parse_obj(sv text) {
+        // (1)
+        const size_t want = std::max<size_t>(1, std::min<size_t>(host_threads(), text.size() / (4u << 20)));
+        std::vector<size_t> cut{0};
+        for (size_t p = 1; p < want; p++) {
+            size_t at = text.find('\n', std::max(cut.back(), text.size() * p / want));
+            if (at == sv::npos || at + 1 >= text.size()) break;
+            if (at + 1 > cut.back()) cut.push_back(at + 1);
+        }
+        cut.push_back(text.size());
+        const size_t n_chunks = cut.size() - 1;
+        std::vector<Chunk> chunks(n_chunks);
+        const bool trace = std::getenv("RRT_LOADER_TRACE") != nullptr;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(now() - a).count(); };
+        auto tA = now();
+        parallel_ranges(n_chunks, 1, [&](size_t b, size_t e, size_t) { for (size_t c = b; c < e; c++) parse_chunk(text.substr(cut[c], cut[c + 1] - cut[c]), chunks[c]); });
+        if (trace) fprintf(stderr, "[loader] %zu chunks tokenised in %.1f ms\n", n_chunks, since(tA));
+        tA = now();
+        // (2) walk in file order: directives, the material of every face, the first failing directive / parse failure
+        std::vector<size_t> off_v(n_chunks + 1, 0), off_vt(n_chunks + 1, 0), off_vn(n_chunks + 1, 0), off_f(n_chunks + 1, 0);
+        for (size_t c = 0; c < n_chunks; c++) {
+            off_v[c + 1] = off_v[c] + chunks[c].v.size(); off_vt[c + 1] = off_vt[c] + chunks[c].vt.size(); off_vn[c + 1] = off_vn[c] + chunks[c].vn.size();
+            off_f[c + 1] = off_f[c] + chunks[c].faces.size();
+        }
+        std::vector<uint32_t> face_mat(off_f[n_chunks], 0);
+        std::optional<uint32_t> current_material;
+        std::optional<Error> stop; size_t stop_face = off_f[n_chunks];         // faces [0, stop_face) precede the first failing directive
+        auto assign = [&](size_t c, size_t from, size_t to) {                   // faces [from, to) of chunk c take the current material
+            if (from >= to) return true;
+            if (!current_material) { stop = Error{RRT_ERR_PARSE, "face before any usemtl"}; stop_face = off_f[c] + from; return false; }   // utils.rs:193 unwrap on None
+            std::fill(face_mat.begin() + off_f[c] + from, face_mat.begin() + off_f[c] + to, *current_material);
+            return true;
+        };
+        for (size_t c = 0; c < n_chunks && !stop; c++) {
+            size_t done = 0;
+            for (const Special& sp : chunks[c].specials) {
+                if (!assign(c, done, sp.face_pos)) break;
+                done = sp.face_pos;
+                try {
+                    if (sp.kind == Special::kError) fail(sp.status, sp.arg);
+                    if (sp.kind == Special::kMtllib) parse_mtl(read_file(dir + sp.arg));                 // utils.rs:168-175
+                    else {                                                                               // utils.rs:176-187
+                        auto it = material_by_name.find(sp.arg);
+                        if (it == material_by_name.end()) fail(RRT_ERR_PARSE, "Material not found, is it in your mtl file?");
+                        current_material = it->second;
+                    }
+                } catch (const Error& e) { stop = e; stop_face = off_f[c] + sp.face_pos; break; }
+            }
+            if (!stop) assign(c, done, chunks[c].faces.size());
+        }
+        if (trace) fprintf(stderr, "[loader] walk %.1f ms\n", since(tA));
+        tA = now();
+        // all "v"/"vt"/"vn" values in file order
+        v.resize(off_v[n_chunks]); vt.resize(off_vt[n_chunks]); vn.resize(off_vn[n_chunks]);
+        parallel_ranges(n_chunks, 1, [&](size_t b, size_t e, size_t) {
+            for (size_t c = b; c < e; c++) {
+                std::copy(chunks[c].v.begin(), chunks[c].v.end(), v.begin() + off_v[c]);
+                std::copy(chunks[c].vt.begin(), chunks[c].vt.end(), vt.begin() + off_vt[c]);
+                std::copy(chunks[c].vn.begin(), chunks[c].vn.end(), vn.begin() + off_vn[c]);
             }
         });
+        if (trace) fprintf(stderr, "[loader] concat %.1f ms\n", since(tA));
+        tA = now();
+        // the faces before the first failing directive, each against the counts of its own line (get_triangle, utils.rs:253-343)
+        m.triangles.resize(stop_face);
+        std::vector<size_t> chunk_of_begin(n_chunks);
+        parallel_ranges(n_chunks, 1, [&](size_t b, size_t e, size_t) {
+            for (size_t c = b; c < e; c++) {
+                const Chunk& C = chunks[c];
+                for (size_t k = 0; k < C.faces.size() && off_f[c] + k < stop_face; k++) {
+                    const FaceRec& f = C.faces[k];
+                    const uint64_t nv = off_v[c] + f.nv, nvt = off_vt[c] + f.nvt, nvn = off_vn[c] + f.nvn;
+                    Triangle& tri = m.triangles[off_f[c] + k];
+                    tri.mat = face_mat[off_f[c] + k];
+                    Vec3* P[3] = {&tri.v1, &tri.v2, &tri.v3}; Vec3* T[3] = {&tri.t1, &tri.t2, &tri.t3}; Vec3* N[3] = {&tri.n1, &tri.n2, &tri.n3};
+                    for (int q = 0; q < 3; q++) {
+                        if (f.bad_k == q) throw FaceError{off_f[c] + k, Error{RRT_ERR_PARSE, C.msgs[f.bad_msg]}};
+                        if (f.vi[q] == 0 || f.vi[q] - 1 >= nv) throw FaceError{off_f[c] + k, Error{RRT_ERR_PARSE, "No vertex with this index"}};   // utils.rs:272-283
+                        *P[q] = v[f.vi[q] - 1];
+                        const uint64_t ti = f.ti[q] - 1, ni = f.ni[q] - 1;                                   // release-mode wrap for index 0 -> out of range -> default
+                        *T[q] = ((f.has_t >> q) & 1u) && ti < nvt ? vt[ti] : Vec3{};                          // utils.rs:285-329
+                        *N[q] = ((f.has_n >> q) & 1u) && ni < nvn ? vn[ni] : Vec3{};
+                    }
+                }
+            }
+        });
+        if (trace) fprintf(stderr, "[loader] faces %.1f ms\n", since(tA));
+        if (stop) throw *stop;
     }
+    struct FaceError { size_t face; Error err; };
 };
 
 }  // namespace
@@ -245,9 +396,23 @@ void load_obj(const std::string& obj_path, const Box& root, Model& out) {
     using clk = std::chrono::steady_clock;
     auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const auto t0 = clk::now();
-    const std::string text = read_file(obj_path);
+    // fs::read_to_string (main.rs:28) as a read-only mapping: the workers fault the pages in while they parse
+    struct Mapping {
+        const char* p = nullptr; size_t n = 0; int fd = -1;
+        ~Mapping() { if (p && n) munmap(const_cast<char*>(p), n); if (fd >= 0) close(fd); }
+    } map;
+    map.fd = open(obj_path.c_str(), O_RDONLY);
+    struct stat st{};
+    if (map.fd < 0 || fstat(map.fd, &st) != 0 || !S_ISREG(st.st_mode)) fail(RRT_ERR_IO, "Could not read file: " + obj_path);
+    map.n = (size_t)st.st_size;
+    if (map.n) {
+        void* q = mmap(nullptr, map.n, PROT_READ, MAP_PRIVATE, map.fd, 0);
+        if (q == MAP_FAILED) { map.n = 0; fail(RRT_ERR_IO, "Could not read file: " + obj_path); }
+        map.p = static_cast<const char*>(q);
+    }
     const auto t1 = clk::now();
-    L.parse_obj(text);
+    try { L.parse_obj(sv(map.p ? map.p : "", map.n)); }
+    catch (const Loader::FaceError& fe) { throw fe.err; }
     const auto t2 = clk::now();
     // the reference pushes each triangle into the octree as it is parsed (utils.rs:196); inserting them afterwards
     // in the same order builds the same tree

@@ -13,6 +13,7 @@
 #include <functional>
 
 #include "model.hpp"
+#include "parallel.hpp"
 
 namespace rrt {
 namespace {
@@ -31,48 +32,56 @@ inline bool touches(const Box& a, const Box& b) {   // Aabb::intersects, aabb.rs
     return true;
 }
 
+// The reference tests the newcomer's box against each of the 8 child boxes (octree.rs:82-104, aabb.rs:49-60).  A triangle that reaches a node
+// touches that node's box (checked at the root, true by induction below it), and the children are the node's box cut at its three mid planes, so
+// per axis "touches the lower half" is exactly !(tb.lo > mid) and "touches the upper half" is exactly !(tb.hi < mid) -- the other two comparisons of
+// the inclusive box test are the ones the parent already passed (NaN coordinates included: every comparison is written as the reference's negation).
+// 6 comparisons per level instead of 48; the number of touched children is the product of the per-axis counts.
 struct Builder {
     std::vector<Box> box;
-    std::vector<uint32_t> first_child, tri_count;
-    std::vector<std::vector<uint32_t>> own;
+    std::vector<uint32_t> first_child, tri_count, own_count;
+    std::vector<double> mid;                      // 3 per node, valid for internal nodes
+    std::vector<uint32_t> tri_node;               // node whose `triangles` Vec holds triangle i (kNowhere: dropped outside the root)
+    static constexpr uint32_t kNowhere = 0xFFFFFFFFu;
 
     uint32_t add_node(const Box& b) {
-        box.push_back(b); first_child.push_back(0); tri_count.push_back(0); own.emplace_back();
+        box.push_back(b); first_child.push_back(0); tri_count.push_back(0); own_count.push_back(0); mid.insert(mid.end(), 3, 0.0);
         return (uint32_t)box.size() - 1;
     }
 
     void split(uint32_t node) {   // Octree::subdivide, octree.rs:121-241
         const Box p = box[node];
-        double mid[3];
-        for (int k = 0; k < 3; k++) mid[k] = p.lo[k] + (p.hi[k] - p.lo[k]) / 2.0;   // octree.rs:136-138, 142-146
+        double m[3];
+        for (int k = 0; k < 3; k++) m[k] = p.lo[k] + (p.hi[k] - p.lo[k]) / 2.0;   // octree.rs:136-138, 142-146
         // (x-half, y-half, z-half) per child in the reference's order; 0 = [lo,mid], 1 = [mid,hi]
         static const int half[8][3] = {{0, 0, 0}, {0, 0, 1}, {1, 0, 1}, {1, 0, 0}, {0, 1, 0}, {0, 1, 1}, {1, 1, 1}, {1, 1, 0}};
         const uint32_t base = (uint32_t)box.size();
         for (int c = 0; c < 8; c++) {
             Box b;
             for (int k = 0; k < 3; k++) {
-                b.lo[k] = half[c][k] ? mid[k] : p.lo[k];
-                b.hi[k] = half[c][k] ? p.hi[k] : mid[k];
+                b.lo[k] = half[c][k] ? m[k] : p.lo[k];
+                b.hi[k] = half[c][k] ? p.hi[k] : m[k];
             }
             add_node(b);
         }
         first_child[node] = base;
+        for (int k = 0; k < 3; k++) mid[3 * (size_t)node + k] = m[k];
     }
 
     void insert(uint32_t tri, const Box& tb) {   // push_triangle + push_at_octant, octree.rs:41-108
+        if (!touches(tb, box[0])) return;         // octree.rs:71-73: silently dropped
+        static const uint32_t child_of[8] = {0, 1, 4, 5, 3, 2, 7, 6};   // index (x-half << 2 | y-half << 1 | z-half) -> child number of `half` above
         uint32_t node = 0;
         for (;;) {
-            if (!touches(tb, box[node])) return;
             tri_count[node] += 1;
             const bool leaf = first_child[node] == 0;
-            if (leaf && own[node].empty()) { own[node].push_back(tri); return; }
+            if (leaf && own_count[node] == 0) { own_count[node] = 1; tri_node[tri] = node; return; }
             if (leaf) split(node);
-            const uint32_t base = first_child[node];
-            int n_touch = 0; uint32_t only = 0;
-            for (uint32_t c = 0; c < 8; c++)
-                if (touches(box[base + c], tb)) { n_touch++; only = base + c; }
-            if (n_touch != 1) { own[node].push_back(tri); return; }
-            node = only;
+            const double* m = &mid[3 * (size_t)node];
+            const bool lx = !(tb.lo[0] > m[0]), hx = !(tb.hi[0] < m[0]), ly = !(tb.lo[1] > m[1]), hy = !(tb.hi[1] < m[1]), lz = !(tb.lo[2] > m[2]), hz = !(tb.hi[2] < m[2]);
+            const int n_touch = ((int)lx + (int)hx) * ((int)ly + (int)hy) * ((int)lz + (int)hz);
+            if (n_touch != 1) { own_count[node] += 1; tri_node[tri] = node; return; }
+            node = first_child[node] + child_of[((uint32_t)hx << 2) | ((uint32_t)hy << 1) | (uint32_t)hz];
         }
     }
 };
@@ -81,20 +90,24 @@ struct Builder {
 
 void build_octree(const std::vector<Triangle>& tris, const Box& root, FlatOctree& out) {
     Builder b;
+    b.tri_node.assign(tris.size(), Builder::kNowhere);
     b.add_node(root);                                 // Octree::new, octree.rs:23-39
-    for (uint32_t i = 0; i < tris.size(); i++) b.insert(i, triangle_box(tris[i]));
+    std::vector<Box> tb(tris.size());
+    parallel_ranges(tris.size(), 1 << 15, [&](size_t lo, size_t hi, size_t) { for (size_t i = lo; i < hi; i++) tb[i] = triangle_box(tris[i]); });
+    for (uint32_t i = 0; i < tris.size(); i++) b.insert(i, tb[i]);   // insertion order decides the tree: serial by nature
 
     const uint32_t n = (uint32_t)b.box.size();
     out.box = std::move(b.box);
     out.first_child = std::move(b.first_child);
     out.tri_count = std::move(b.tri_count);
+    // every node's `triangles` Vec in insertion order == increasing triangle index: a counting sort by node
     out.own_off.assign(n + 1, 0);
-    out.own_idx.clear();
-    for (uint32_t i = 0; i < n; i++) {
-        out.own_off[i] = (uint32_t)out.own_idx.size();
-        out.own_idx.insert(out.own_idx.end(), b.own[i].begin(), b.own[i].end());
+    for (uint32_t i = 0; i < n; i++) out.own_off[i + 1] = out.own_off[i] + b.own_count[i];
+    out.own_idx.assign(out.own_off[n], 0);
+    {
+        std::vector<uint32_t> fill(out.own_off.begin(), out.own_off.end() - 1);
+        for (uint32_t i = 0; i < tris.size(); i++) if (b.tri_node[i] != Builder::kNowhere) out.own_idx[fill[b.tri_node[i]]++] = i;
     }
-    out.own_off[n] = (uint32_t)out.own_idx.size();
 
     // depth (root = 1): children always have larger ids than their parent, so one forward sweep suffices
     std::vector<uint32_t> depth(n, 0);

@@ -1163,6 +1163,15 @@ __global__ __launch_bounds__(64) void intersect_kernel(const DevScene S, uint32_
 
 }  // namespace
 
+// Forces the code object of this library onto the current device (HIP loads it lazily, ~80 ms for these kernels): called from a helper thread
+// while the host is still parsing the scene (api.cpp, warm_device_async).
+void preload_kernels() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&render_kernel<true, false>));
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&render_kernel<false, false>));
+    (void)hipGetLastError();
+}
+
 uint32_t stack_bytes_per_wave(uint32_t levels) { return kParkBytes + levels * kLevelBytes; }
 
 #ifdef RRT_DEV_HSACO
