@@ -147,12 +147,16 @@ __device__ __forceinline__ UHead load_uhead(const RRT_CONSTANT DevNode* p) {
     return n;
 }
 struct UPlanes { double lo[3], hi[3], mid[3]; };
+// (four independent 16-byte loads, issued together: one round trip like a single 64-byte load, but four register tuples of 4 instead of one of 16 --
+// the allocator evicts a tuple WHOLE when it wants two of its registers, which with the 16-tuple cost 16 v_writelane + 16 v_readlane on every visit)
 __device__ __forceinline__ UPlanes load_uplanes(const RRT_CONSTANT DevNode* p, double mid2) {
-    const u32x16 a = *(const RRT_CONSTANT u32x16*)p;
+    // (each address passes through an empty asm: otherwise the load/store optimizer fuses the four loads back into one s_load_dwordx16)
+    const RRT_CONSTANT u32x4* q = (const RRT_CONSTANT u32x4*)p;
+    const u32x4 a = *own_sgprs(q), b = *own_sgprs(q + 1), c = *own_sgprs(q + 2), d = *own_sgprs(q + 3);
     UPlanes n;
-    n.lo[0] = mkd(a[0], a[1]); n.lo[1] = mkd(a[2], a[3]); n.lo[2] = mkd(a[4], a[5]);
-    n.hi[0] = mkd(a[6], a[7]); n.hi[1] = mkd(a[8], a[9]); n.hi[2] = mkd(a[10], a[11]);
-    n.mid[0] = mkd(a[12], a[13]); n.mid[1] = mkd(a[14], a[15]); n.mid[2] = mid2;
+    n.lo[0] = mkd(a[0], a[1]); n.lo[1] = mkd(a[2], a[3]); n.lo[2] = mkd(b[0], b[1]);
+    n.hi[0] = mkd(b[2], b[3]); n.hi[1] = mkd(c[0], c[1]); n.hi[2] = mkd(c[2], c[3]);
+    n.mid[0] = mkd(d[0], d[1]); n.mid[1] = mkd(d[2], d[3]); n.mid[2] = mid2;
     return n;
 }
 

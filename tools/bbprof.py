@@ -185,10 +185,54 @@ def report(counts_path=COUNTS, map_path=MAP, out_json=None):
     return result
 
 
+REGION_MARKS = [("walk set-up (fp32 ray, reciprocals, bundle)", "__device__ __forceinline__ void traverse("),
+                ("pick node + record load", "const unsigned long long pending = __builtin_amdgcn_ballot_w64(!done);"),
+                ("children: fp32 reach filter", "conservative fp32 filter against the TIGHT"),
+                ("children: single candidate (exact slab test, leaf triangle)", "if ((reach & (reach - 1u)) == 0u) {"),
+                ("children: several candidates (plane quotients, slab tests, leaf triangles, rank)", "double qlx = 0"),
+                ("own list: boxes in lanes", "bool in_lanes = kBundle;"),
+                ("own list: one box at a time (lane filter)", "a node with a single super-cluster carries its slot range in the node record and skips"),
+                ("return / push / unwind", "bool returning;"),
+                ("shading + per-ray state machine", "// ------------------------------------------------------------------------------------------------ shading helpers"),
+                ("kernel prologue / epilogue (pixel grid, Color::mix, store)", "// ------------------------------------------------------------------------------------------------ kernels")]
+
+
+def regions(counts_path=COUNTS, map_path=MAP):
+    """Dynamic VALU per region of the kernel: a block belongs to the region of the LAST marker line at or before the largest traverse-or-later
+    source line among its instructions; blocks made only of inlined helper lines inherit the region of the block before them in layout order."""
+    kernels = json.load(open(map_path))["kernels"]
+    src = open(os.path.join(CSRC, "render.hip")).read().split("\n")
+    marks = [(nm, next(i + 1 for i, l in enumerate(src) if key in l)) for nm, key in REGION_MARKS]
+    first = marks[0][1]
+    launches = collections.Counter(); sums = {}
+    for rec in open(counts_path).read().strip().split("\n"):
+        name, vals = rec.split(" ", 1)
+        v = list(map(int, vals.split())); launches[name] += 1
+        sums[name] = [a + b for a, b in zip(sums.get(name, [0] * len(v)), v)]
+    out = {}
+    for name, n in launches.most_common():
+        blocks = kernels[name]["blocks"]; cnt = [c / n for c in sums[name][:len(blocks)]]
+        tot = collections.Counter(); prev = marks[-1][0]
+        for b, c in zip(blocks, cnt):
+            ls = [l for op, l in b["ops"] if l >= first]
+            reg = [nm for nm, ln in marks if ln <= max(ls)][-1] if ls else prev
+            prev = reg
+            tot[reg] += c * sum(1 for op, l in b["ops"] if op.startswith("v_"))
+        T = sum(tot.values()) or 1
+        print(f"\n=== {name} ({n} launches): VALU per launch {T:,.0f}")
+        for k, v in tot.most_common():
+            print(f"   {100 * v / T:5.1f} %  {v:16,.0f}  {k}")
+        out[name] = dict(tot)
+    return out
+
+
 if __name__ == "__main__":
     cmd = sys.argv[1] if len(sys.argv) > 1 else "build"
     if cmd == "build": build()
     elif cmd == "run": run(sys.argv[2:])
+    elif cmd == "regions":
+        a = sys.argv[2:]
+        regions(a[0] if a else COUNTS, a[1] if len(a) > 1 else MAP)
     elif cmd == "report":
         a = sys.argv[2:]
         report(a[0] if a else COUNTS, a[1] if len(a) > 1 else MAP, a[2] if len(a) > 2 else None)
