@@ -82,8 +82,10 @@ def main() -> None:
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scene", default=os.path.join(ROOT, "assets", "model2.obj"))
     ap.add_argument("--pipeline-depth", type=int, default=4, help="N > 1: frames in flight (gather + de-tiling of a frame overlap the tracing of the next); 0 = plain one-frame-at-a-time step")
-    ap.add_argument("--gather", choices=("lib", "torch"), default="lib", help="N > 1: `lib` = the library's own RCCL gather (rrt_dist_create / rrt_multi_enqueue: partition, gather "
-                    "and de-tiling behind the C ABI); `torch` = the same choreography issued from here with torch.distributed.gather")
+    ap.add_argument("--gather", choices=("auto", "lib", "torch"), default="auto", help="N > 1: `lib` = the library's own RCCL gather (rrt_dist_create / rrt_multi_enqueue: partition, "
+                    "gather and de-tiling behind the C ABI); `torch` = the same choreography issued from here with torch.distributed.gather; `auto` = K steps of each, "
+                    "torch first, the library under a watchdog, the faster one reported (both in `gather_paths`)")
+    ap.add_argument("--lib-timeout", type=float, default=120.0, help="--gather auto: seconds the library path may take before the torch result is reported alone")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-fb", action="store_true", help="skip the boundary-inclusive rrt_render timings (frame_ms_host_fb)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the bounded cpu_baseline leg (3 samples)")
@@ -168,25 +170,27 @@ def main() -> None:
         tpr = rrt.tiles_per_rank(W, H, world)
         want_pipeline = args.pipeline_depth > 0
         DEPTH = max(1, args.pipeline_depth)
-        use_lib = args.gather == "lib" and not rehearsal
         lib_mg = None
-        if use_lib:
-            # (a) local: bind RCCL inside the library (dlopen) -- no communication yet; the ranks agree before the collective ncclCommInitRank
-            ok = 1
+        lib_state = {"stage": "not started", "error": None}
+
+        def lib_init():
+            """The library's own gather: (a) local -- bind RCCL inside the library (dlopen), no communication; the ranks agree; (b) collective --
+            ncclCommInitRank with rank 0's id."""
+            lib_state["stage"] = "binding RCCL inside the library (dlopen)"
+            ok, err, uid = 1, None, None
             try:
                 uid = rrt.MultiGpu.unique_id()
             except Exception as e:                                                       # noqa: BLE001
-                ok = 0; pipeline_error = f"rank {rank}: {type(e).__name__}: {e}"
+                ok = 0; err = f"rank {rank}: {type(e).__name__}: {e}"
             flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 0:
-                use_lib = False; pipeline_fallback = True
-                pipeline_error = pipeline_error or "another rank could not bind RCCL inside the library"
-                print(f"[bench rank {rank}] library gather unavailable ({pipeline_error}); using the torch.distributed gather", file=sys.stderr, flush=True)
-            else:
-                idt = torch.frombuffer(bytearray(uid), dtype=torch.uint8).cuda()
-                dist.broadcast(idt, src=0)
-                lib_mg = rrt.MultiGpu.dist(rt, rank, world, bytes(idt.cpu().numpy().tobytes()), frames_in_flight=DEPTH)   # collective
+                lib_state["error"] = err or "another rank could not bind RCCL inside the library"
+                return None
+            idt = torch.frombuffer(bytearray(uid), dtype=torch.uint8).cuda()
+            dist.broadcast(idt, src=0)
+            lib_state["stage"] = "ncclCommInitRank (rrt_dist_create)"
+            return rrt.MultiGpu.dist(rt, rank, world, bytes(idt.cpu().numpy().tobytes()), frames_in_flight=DEPTH)   # collective
         ok = 1
         try:
             # Frames in flight: frame i's gather (RCCL stream) and de-tiling (side stream on GPU 0) overlap the tracing of frame i+1, so each of
@@ -254,14 +258,9 @@ def main() -> None:
                     if i is not None: gather_ev[i][1].record(side)
                     detile_done[b].record(side); detile_pending[b] = True
 
-        lib_enqueue = lib_mg.bind_enqueue(fb if rank == 0 else None, W, H) if lib_mg is not None else None
-
-        def lib_step(i):
-            lib_enqueue()                                        # trace -> grouped RCCL send/recv to rank 0 -> de-tile, all enqueued inside the library
-
-        def step(i):
+        def torch_step(i):
             try:
-                lib_step(i) if lib_mg is not None else simple_step(i) if simple[0] else pipelined_step(i)
+                simple_step(i) if simple[0] else pipelined_step(i)
             except Exception as e:                               # noqa: BLE001 -- collectives are in flight: no safe fallback from here
                 print(f"[bench rank {rank}] step failed after collectives were issued ({type(e).__name__}: {e}); aborting", file=sys.stderr, flush=True)
                 try:
@@ -269,18 +268,18 @@ def main() -> None:
                 finally:
                     os._exit(3)
 
-        def fence():
+        def torch_fence():
             set_stream(default_stream)
-            if lib_mg is not None: lib_mg.sync()
             for w in gather_work:
                 if w is not None: w.wait()
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
 
+        step, fence = torch_step, torch_fence
         # one full pipelined step per slot, then agree again: a rank whose pipelined choreography misbehaves WITHOUT raising (wrong frame) cannot be
         # detected here, but a rank that sees an error state on its streams can still vote for the plain step before the timed region
-        if not simple[0] or lib_mg is not None:
+        if not simple[0] and args.gather != "lib":
             for _ in range(DEPTH): step(None)
             fence()
             ok = 1
@@ -294,37 +293,43 @@ def main() -> None:
                 pipeline_fallback = True; simple[0] = True
                 for k in range(DEPTH): gather_work[k] = None; detile_pending[k] = False
 
-    torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step(None)
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    host_enqueue_ms = (time.perf_counter() - t0) / args.steps * 1e3   # host time to issue one step (launch + gather + de-tile calls), before any waiting
-    fence()
-    elapsed = time.perf_counter() - t0
-    if multi and lib_mg is not None:
-        kernel_ms = float(rt.last_stats()["kernel_ms"])             # library path: HIP events around the rank's last trace launch, on its slot's stream
-    else:
-        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))   # trace kernel only, HIP events on its launch stream
-    kernel_ms_min = kernel_ms_max = kernel_ms
-    gather_ms = None
-    if multi:
-        t = torch.tensor([elapsed, kernel_ms, -kernel_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms_max, kernel_ms_min = float(t[0]), float(t[1]), -float(t[2])
-        kernel_ms = kernel_ms_max
-        if rank == 0 and lib_mg is not None:
-            gather_ms = lib_mg.last_gather_ms()                      # rank 0's stream: own tiles traced -> frame de-tiled (wait for the slowest peer + gather + de-tile), last frame
-        elif rank == 0 and gather_ev and not simple[0] and not rehearsal:
-            gather_ms = float(np.mean([a.elapsed_time(b) for a, b in gather_ev]))   # side stream: wait for the RCCL gather of the slot + de-tile
+    def measure(step, fence, lib=None):
+        """W untimed warm-up steps, then exactly K steps between two fences (barrier + synchronize); MAX over ranks."""
+        torch.cuda.synchronize()
+        for _ in range(args.warmup):
+            step(None)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        host_enqueue_ms = (time.perf_counter() - t0) / args.steps * 1e3   # host time to issue one step (launch + gather + de-tile calls), before any waiting
+        fence()
+        elapsed = time.perf_counter() - t0
+        if lib is not None:
+            kernel_ms = float(rt.last_stats()["kernel_ms"])         # library path: HIP events around the rank's last trace launch, on its slot's stream
+        else:
+            kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))   # trace kernel only, HIP events on its launch stream
+        m = {"elapsed": elapsed, "kernel_ms": kernel_ms, "kernel_ms_min": kernel_ms, "kernel_ms_max": kernel_ms, "gather_ms": None, "host_enqueue_ms": host_enqueue_ms}
+        if multi:
+            t = torch.tensor([elapsed, kernel_ms, -kernel_ms], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            m["elapsed"], m["kernel_ms_max"], m["kernel_ms_min"] = float(t[0]), float(t[1]), -float(t[2])
+            m["kernel_ms"] = m["kernel_ms_max"]
+            if rank == 0 and lib is not None:
+                m["gather_ms"] = lib.last_gather_ms()               # rank 0's stream: own tiles traced -> frame de-tiled (wait for the slowest peer + gather + de-tile), last frame
+            elif rank == 0 and gather_ev and not simple[0] and not rehearsal:
+                m["gather_ms"] = float(np.mean([a.elapsed_time(b) for a, b in gather_ev]))   # side stream: wait for the RCCL gather of the slot + de-tile
+        if rank == 0:
+            m["frame"] = fb.cpu().numpy().view(np.uint32).copy()
+        return m
 
-    if rank == 0:
+    def build_out(m, gather_label):
         traced_rows = 2 * (H // 2) - 1                       # y = -H/2 is computed by the reference but its pixels are rejected by put_pixel; not traced here
         rays_primary = 4 * (2 * (W // 2)) * traced_rows
+        elapsed, kernel_ms, kernel_ms_min, kernel_ms_max, gather_ms, host_enqueue_ms = m["elapsed"], m["kernel_ms"], m["kernel_ms_min"], m["kernel_ms_max"], m["gather_ms"], m["host_enqueue_ms"]
+        in_lib = gather_label == "lib"
         ms_per_step = elapsed / args.steps * 1e3
-        frame = fb.cpu().numpy().view(np.uint32)
+        frame = m["frame"]
         workload_key = f"{'soup' + str(sd.info['n_tris']) if scene_name.startswith('soup') else scene_name}@{W}x{H}"
 
         # --- boundary-inclusive frame: rrt_render into a HOST framebuffer, as the Rust host's Canvas.buffer receives it (engine.rs:127,246-250)
@@ -360,7 +365,7 @@ def main() -> None:
             pass
 
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not multi and not args.no_cpu_baseline:
             from oracle import binding as ob                  # checker / reported baseline only
             pos, uv, nrm, mat = sd.triangles()
             osc = ob.OracleScene(pos, uv, nrm, mat, sd.materials(), sd.textures(), [(l.kind, l.intensity, (l.v.x, l.v.y, l.v.z)) for l in lights], (0.0, 2.0, -10.0))
@@ -457,23 +462,93 @@ def main() -> None:
                "data": "reference scene assets/model2.obj (teapot+table+mirror, 6334 triangles), camera/lights of main.rs" if teapot else f"synthetic ({scene_name}: SURVEY.md 8d soup recipe)" if scene_name.startswith("soup") else f"reference scene {scene_name}",
                "config": {"workload": f"{scene_name} {W}x{H}, 4 sub-samples/pixel, shadow rays + depth-5 mirror reflection, f64",
                           "rays_primary_per_frame": rays_primary,
-                          "partition": "single launch" if not multi else f"8x8-pixel tiles round-robin over {world} GPUs + RCCL gather to GPU 0, " + (f"inside the library (rrt_multi_enqueue), {DEPTH} frames in flight" if lib_mg is not None else "torch.distributed.gather, " + ("one frame at a time" if simple[0] else f"{DEPTH} frames in flight (one stream per slot)")),
+                          "partition": "single launch" if not multi else f"8x8-pixel tiles round-robin over {world} GPUs + RCCL gather to GPU 0, " + (f"inside the library (rrt_multi_enqueue), {DEPTH} frames in flight" if in_lib else "torch.distributed.gather, " + ("one frame at a time" if simple[0] else f"{DEPTH} frames in flight (one stream per slot)")),
                           "octree_nodes": sd.info["n_nodes"], "triangles": sd.info["n_tris"], "filter_variant": "bundle" if rt.last_stats()["filter_variant"] else "lane"},
                "frame_ms": round(ms_per_step, 4), "kernel_ms": round(kernel_ms, 4), "host_enqueue_ms_per_step": round(host_enqueue_ms, 4), "setup_ms": setup,
                **({"rehearsal": "gloo on one GPU: NOT a benchmark result"} if rehearsal else {}),
                "frame_checksum": int(np.bitwise_xor.reduce(frame.ravel().astype(np.uint64) * np.arange(1, frame.size + 1, dtype=np.uint64)))}
         if multi:
-            out.update({"gather": "lib" if lib_mg is not None else "torch", "pipeline_fallback": pipeline_fallback, "pipeline_error": pipeline_error, "kernel_ms_per_rank_min": round(kernel_ms_min, 4),
+            out.update({"gather": gather_label, "pipeline_fallback": pipeline_fallback, "pipeline_error": pipeline_error, "kernel_ms_per_rank_min": round(kernel_ms_min, 4),
                         "kernel_ms_per_rank_max": round(kernel_ms_max, 4), "gather_ms": round(gather_ms, 4) if gather_ms is not None else None})
         if host_fb is not None:
             out.update({"frame_ms_host_fb": host_fb["frame_ms_host_fb"], "host_fb": host_fb})
         out["roofline"] = roofline
         if cpu is not None:
             out["cpu_baseline"] = cpu
+        return out
+
+    def emit(out):
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
+
+    # ---- the measurement(s)
+    paths = {}
+    if not multi:
+        res = measure(step, fence)
+        if rank == 0: emit(build_out(res, None))
+    else:
+        first = "lib" if args.gather == "lib" else "torch"
+        out_first = None
+        if first == "torch":
+            res = measure(torch_step, torch_fence)
+            if rank == 0:
+                out_first = build_out(res, "torch")
+                paths["torch"] = {"value": out_first["value"], "ms_per_step": out_first["ms_per_step"], "gather_ms": out_first.get("gather_ms"), "host_enqueue_ms_per_step": out_first["host_enqueue_ms_per_step"],
+                                  "frames_in_flight": 1 if simple[0] else DEPTH}
+        if args.gather in ("auto", "lib") and not rehearsal:
+            # the library's gather has the cheaper host side (one C call per frame); under `auto` it runs behind the torch result, guarded by a
+            # watchdog: if it does not finish in time the torch line is printed alone (with the stage it hung in) and the process ends cleanly
+            import threading
+            finished = threading.Event()
+
+            def watchdog():
+                if finished.wait(args.lib_timeout): return
+                msg = f"library gather did not finish within {args.lib_timeout:.0f} s (stage: {lib_state['stage']})"
+                print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
+                if rank == 0 and out_first is not None:
+                    out_first["gather_paths"] = dict(paths, lib={"error": msg})
+                    emit(out_first)
+                os._exit(0 if out_first is not None or rank != 0 else 4)
+            if args.gather == "auto":
+                threading.Thread(target=watchdog, daemon=True).start()
+            lib_mg = lib_init()
+            out_lib = None
+            if lib_mg is not None:
+                lib_state["stage"] = "first frames through rrt_multi_enqueue"
+                lib_enqueue = lib_mg.bind_enqueue(fb if rank == 0 else None, W, H)
+
+                def lib_step(i):
+                    lib_enqueue()                                # trace -> grouped RCCL send/recv to rank 0 -> de-tile, all enqueued inside the library
+
+                def lib_fence():
+                    set_stream(default_stream)
+                    lib_mg.sync()
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                    torch.cuda.synchronize()
+                for _ in range(DEPTH): lib_step(None)
+                lib_fence()
+                lib_state["stage"] = "timed steps"
+                res = measure(lib_step, lib_fence, lib=lib_mg)
+                if rank == 0:
+                    out_lib = build_out(res, "lib")
+                    paths["lib"] = {"value": out_lib["value"], "ms_per_step": out_lib["ms_per_step"], "gather_ms": out_lib.get("gather_ms"), "host_enqueue_ms_per_step": out_lib["host_enqueue_ms_per_step"],
+                                    "frames_in_flight": DEPTH, "same_frame_as_torch_path": (out_first is None or out_lib["frame_checksum"] == out_first["frame_checksum"])}
+            else:
+                paths["lib"] = {"error": lib_state["error"]}
+            finished.set()
+            if rank == 0:
+                best = out_lib if (out_lib is not None and (out_first is None or (out_lib["value"] >= out_first["value"] and paths["lib"].get("same_frame_as_torch_path", True)))) else out_first
+                if best is None:
+                    raise SystemExit(f"bench.py: no N > 1 path completed ({paths})")
+                best["gather_paths"] = paths
+                emit(best)
+        elif rank == 0:
+            out_first["gather_paths"] = paths
+            emit(out_first)
+
 
     if multi:
         dist.barrier()

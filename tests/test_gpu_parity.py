@@ -455,10 +455,13 @@ def test_bench_multi_gpu_choreography_single_rank():
         assert len(lines) == 1, r.stdout
         return json.loads(lines[0])
     single = run({})
-    inlib = run({"RRT_BENCH_FORCE_DIST": "1"})                                            # default: the library's own gather (rrt_dist_create / rrt_multi_enqueue)
+    both = run({"RRT_BENCH_FORCE_DIST": "1"})                                             # default (auto): K steps of each path, the faster one reported
+    inlib = run({"RRT_BENCH_FORCE_DIST": "1"}, "--gather", "lib")                         # the library's own gather (rrt_dist_create / rrt_multi_enqueue)
     piped = run({"RRT_BENCH_FORCE_DIST": "1"}, "--gather", "torch")
     plain = run({"RRT_BENCH_FORCE_DIST": "1"}, "--gather", "torch", "--pipeline-depth", "0")
-    assert single["frame_checksum"] == inlib["frame_checksum"] == piped["frame_checksum"] == plain["frame_checksum"]
+    assert single["frame_checksum"] == inlib["frame_checksum"] == piped["frame_checksum"] == plain["frame_checksum"] == both["frame_checksum"]
+    assert set(both["gather_paths"]) == {"torch", "lib"} and both["gather_paths"]["lib"]["same_frame_as_torch_path"] is True
+    assert both["gather"] in ("lib", "torch") and both["value"] == max(both["gather_paths"]["lib"]["value"], both["gather_paths"]["torch"]["value"])
     assert single["n_gpus"] == 1 and single["unit"] == "Mrays/s"
     assert inlib["gather"] == "lib" and piped["gather"] == "torch" and inlib["pipeline_fallback"] is False and inlib["gather_ms"] is not None
     assert "frame_ms_host_fb" in single and single["host_fb"]["identical_to_device_frame"] and "setup_ms" in single
