@@ -51,8 +51,10 @@ typedef struct { rrt_vec3 ka, kd, ks; double ns, kr; int32_t tex, bump; } rrt_ma
 typedef struct { const uint8_t *rgb; uint32_t width, height; } rrt_texture;
 
 /* RRT_FLAG_NO_CULL: walk every node's triangle list in full, in list order, exactly as ray.rs:119-129 does (no cluster boxes).
- * Default (0): the lists are indexed by padded cluster boxes that skip triangles a ray cannot reach; results are identical
- * (DESIGN.md section 4), tests compare the two modes bit for bit. */
+ * Default (0): the lists are indexed by padded cluster boxes that skip triangles a ray cannot reach.  Results are identical for every ray that does
+ * not lie IN a triangle's plane to within rounding noise (where the reference's own Moller-Trumbore answer is noise): DESIGN.md section 4 gives the
+ * bound.  Rays from the raytracer's origin -- every primary ray -- are guarded against that case too (rrt_stats.origin_plane_triangles); secondary
+ * rays are not.  Tests compare the two modes bit for bit on every config and on 10^6 constructed near-coplanar rays. */
 #define RRT_FLAG_NO_CULL 1u
 /* The index boxes are tested either by every ray against one box at a time (LANE filter) or by 64 boxes at a time against the wave's ray
  * bundle (BUNDLE filter; faster on coherent rays, slower on scattered ones).  Both give the same pixels.  By default the first frame of
