@@ -6,7 +6,7 @@ set -u
 TAG=${1:-r02}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 STEPS=${STEPS:-50}
 BENCH="python3 $ROOT/bench.py --steps $STEPS --warmup 5 --no-cpu-baseline --no-host-fb $*"
