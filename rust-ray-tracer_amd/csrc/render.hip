@@ -312,10 +312,16 @@ __device__ __forceinline__ bool origin_ray_in_suspect_plane(const DevScene& S, V
 struct Prof { unsigned long long c[16]; unsigned long long t[8]; unsigned long long last; };
 #define PROF_DECL Prof& prof,
 #define PROF_ARG prof,
+// Counters are per WAVE: whichever lane is the first active one at the increment adds to its own copy, and every lane's copies are summed at the end
+// (an increment under divergent control flow therefore counts once per wave that reaches it, whatever lanes are active).
+__device__ __forceinline__ bool prof_leader() {
+    const unsigned long long e = __builtin_amdgcn_ballot_w64(true);
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(e >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)e, 0u)) == 0u;
+}
 #ifdef RRT_PROF_HIST   /* histogram build: only the histogram counters (written as 100 + index) count */
-#define PROF_ADD(i, x) ((i) >= 100 ? (void)(prof.c[(i) >= 100 ? (i) - 100 : 0] += (unsigned long long)(x)) : (void)0)
+#define PROF_ADD(i, x) do { const unsigned long long _v = (unsigned long long)(x); if ((i) >= 100) prof.c[(i) >= 100 ? (i) - 100 : 0] += prof_leader() ? _v : 0ull; } while (0)
 #else
-#define PROF_ADD(i, x) (prof.c[i] += (unsigned long long)(x))
+#define PROF_ADD(i, x) do { const unsigned long long _v = (unsigned long long)(x); prof.c[i] += prof_leader() ? _v : 0ull; } while (0)   /* x (a ballot, usually) is evaluated by every active lane */
 #endif
 #define PROF_T(i) do { const unsigned long long _n = __builtin_amdgcn_s_memtime(); prof.t[i] += _n - prof.last; prof.last = _n; } while (0)
 #else
@@ -1102,7 +1108,8 @@ __global__ __launch_bounds__(64, kBundle ? RRT_WAVES_BUNDLE : RRT_WAVES_LANE) vo
     const uint32_t c = trace_colour<kBundle, kGroups>(PROF_ARG S, stk, traced, ld3(S.origin), dir);
 #ifdef RRT_PROFILE
     PROF_T(4);
-    if (lane == 0) { for (int i = 0; i < 16; i++) if (prof.c[i]) atomicAdd(S.prof + i, prof.c[i]); for (int i = 0; i < 8; i++) if (prof.t[i]) atomicAdd(S.prof + 16 + i, prof.t[i]); }
+    for (int i = 0; i < 16; i++) if (prof.c[i]) atomicAdd(S.prof + i, prof.c[i]);
+    if (lane == 0) { for (int i = 0; i < 8; i++) if (prof.t[i]) atomicAdd(S.prof + 16 + i, prof.t[i]); }
 #endif
     // Color::mix over the 4 sub-samples of the pixel = 4 consecutive lanes (entities.rs:49-69): u64 sums, truncating /4
     uint32_t r = (c >> 16) & 255u, g = (c >> 8) & 255u, b = c & 255u;

@@ -66,3 +66,21 @@ def test_cpp_host_mirror_builds_and_links(rrt):
     if rrt.device_count() == 0:
         r = subprocess.run([cli, os.path.join(ROOT, "assets", "model2.obj"), "/dev/null", "16", "16"], capture_output=True, text=True)
         assert r.returncode == 1 and "no usable HIP device" in r.stderr, r.stderr
+
+
+def test_round2_entry_points_validate_their_arguments_without_a_gpu(rrt, teapot):
+    """The multi-GPU, host-buffer and set-up-time entry points reject bad arguments with status codes (no GPU needed), and a model reports the
+    wall time of its set-up stages."""
+    import ctypes as C
+    L = rrt.lib()
+    out = C.c_void_p()
+    assert L.rrt_multi_create(None, 0, 1, 0, C.byref(out)) == rrt.ERR_INVALID_ARG
+    assert L.rrt_dist_create(None, 0, 1, None, 1, C.byref(out)) == rrt.ERR_INVALID_ARG
+    assert L.rrt_multi_enqueue(None, 64, 48, None) == rrt.ERR_INVALID_ARG and L.rrt_multi_sync(None) == rrt.ERR_INVALID_ARG
+    assert L.rrt_render_multi(None, 64, 48, None) == rrt.ERR_INVALID_ARG
+    assert L.rrt_host_buffer_register(None, 0) == rrt.ERR_INVALID_ARG and L.rrt_host_buffer_unregister(None) == rrt.ERR_INVALID_ARG
+    L.rrt_multi_destroy(None)                                           # a no-op, like free(NULL)
+    t = rrt.CSetupTimes()
+    assert L.rrt_get_setup_times(teapot._h, None, C.byref(t)) == rrt.OK
+    assert t.parse_ms > 0 and t.texture_ms > 0 and t.octree_ms > 0 and t.index_ms == 0 and t.upload_ms == 0
+    assert L.rrt_get_setup_times(None, None, None) == rrt.ERR_INVALID_ARG
