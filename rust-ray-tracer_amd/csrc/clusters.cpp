@@ -41,6 +41,27 @@ TriBox tri_box(const Triangle& t) {
 float round_down(double x) { float f = (float)x; if ((double)f > x) f = std::nextafterf(f, -FLT_MAX); return std::isfinite(f) ? f : -FLT_MAX; }
 float round_up(double x) { float f = (float)x; if ((double)f < x) f = std::nextafterf(f, FLT_MAX); return std::isfinite(f) ? f : FLT_MAX; }
 
+// (lo, hi) -> (centre, half-extent), in place, for one record's six floats (device_scene.hpp).  lo/hi are already padded and rounded outward;
+// the half-extent is rounded up once more, so the new box contains the old one whatever the rounding of the centre.
+void to_centre_half(float* lo, float* hi) {
+    for (int k = 0; k < 3; k++) {
+        const double L = lo[k], H = hi[k];
+        float c, h;
+        if (L > H) { c = 0.0f; h = -FLT_MAX; }                                   // empty: never hit
+        else if (L <= -FLT_MAX || H >= FLT_MAX) { c = 0.0f; h = FLT_MAX; }     // unbounded (no-cull index): always hit
+        else {
+            c = (float)((L + H) * 0.5);
+            h = round_up(std::max((double)c - L, H - (double)c));
+            h = std::nextafterf(h, FLT_MAX);                                   // (the differences above are rounded doubles: one more ulp covers that)
+            if (!std::isfinite(c) || !std::isfinite(h)) { c = 0.0f; h = FLT_MAX; }
+        }
+        lo[k] = c; hi[k] = h;
+    }
+}
+template <class Rec> void boxes_to_centre_half(std::vector<Rec>& v) {
+    parallel_ranges(v.size(), 1 << 16, [&](size_t b, size_t e, size_t) { for (size_t i = b; i < e; i++) to_centre_half(v[i].lo, v[i].hi); });
+}
+
 // recursively split items[begin,end) (indices into `boxes`) until every part holds <= leaf items; emits [begin,end) ranges in order
 void split(std::vector<uint32_t>& items, size_t begin, size_t end, size_t leaf, const std::vector<TriBox>& boxes, std::vector<std::pair<size_t, size_t>>& out) {
     if (end - begin <= leaf) { out.emplace_back(begin, end); return; }
@@ -233,6 +254,8 @@ void build_clusters(const Model& m, bool enable_cull, ClusterSet& out) {
         }
     });
     for (int i = 0; i < 8; i++) out.child_boxes.push_back(DevClusterBox{});
+    // ---- device form of every box record (the spare all-zero records become the point box at the origin: they are only ever read past a count)
+    boxes_to_centre_half(out.supers); boxes_to_centre_half(out.cboxes); boxes_to_centre_half(out.tboxes); boxes_to_centre_half(out.child_boxes);
 }
 
 namespace {

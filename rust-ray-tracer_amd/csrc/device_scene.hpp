@@ -35,8 +35,12 @@ static_assert(sizeof(DevTriGeom) == 80, "DevTriGeom must be 80 bytes");
 // A super-cluster owns the slots [tri_begin, tri_begin + tri_count), tri_begin a multiple of 8, tri_count <= 64; its cluster c is the
 // 8 slots from tri_begin + 8c, and the box of the cluster that starts at slot s is cboxes[s / 8].  Slots between the end of a
 // super-cluster and the next multiple of 8 are padding (all-zero geometry, never hit).
-struct DevSuper { float lo[3], hi[3]; uint32_t tri_begin, tri_count; };     // 32 B
-struct DevClusterBox { float lo[3], hi[3]; uint32_t _pad[2]; };             // 32 B
+// Box records.  While clusters.cpp builds the index they hold (lo, hi); build_clusters ends by rewriting every record IN PLACE to the device
+// form (centre, half-extent) with [c - h, c + h] a superset of [lo, hi] (boxes_to_centre_half): the kernels' slab tests take the near and far
+// plane of an axis as one packed FMA  c*inv + n -/+ h*|inv|  instead of two FMAs and a min/max pair.  An empty box is (0, -FLT_MAX): never
+// hit; a box of the no-cull index is (0, FLT_MAX): always hit.
+struct DevSuper { union { float lo[3]; float c[3]; }; union { float hi[3]; float h[3]; }; uint32_t tri_begin, tri_count; };     // 32 B
+struct DevClusterBox { union { float lo[3]; float c[3]; }; union { float hi[3]; float h[3]; }; uint32_t _pad[2]; };             // 32 B
 static_assert(sizeof(DevClusterBox) == 32 && sizeof(DevSuper) == 32, "cluster records must be 32 bytes");
 
 struct DevTriAttr {                                                // 128 B: one cache line per shaded hit

@@ -160,8 +160,8 @@ __device__ __forceinline__ UPlanes load_uplanes(const RRT_CONSTANT DevNode* p, d
     return n;
 }
 
-struct UBox { float lox, loy, loz, hix, hiy, hiz; uint32_t a, b; };   // DevSuper (a = tri_begin, b = tri_count) or DevClusterBox
-__device__ __forceinline__ UBox mk_ubox(u32x8 r) { UBox x; x.lox = mkf(r[0]); x.loy = mkf(r[1]); x.loz = mkf(r[2]); x.hix = mkf(r[3]); x.hiy = mkf(r[4]); x.hiz = mkf(r[5]); x.a = r[6]; x.b = r[7]; return x; }
+struct UBox { float cx, cy, cz, hx, hy, hz; uint32_t a, b; };   // centre and half-extent (device_scene.hpp); DevSuper (a = tri_begin, b = tri_count) or DevClusterBox
+__device__ __forceinline__ UBox mk_ubox(u32x8 r) { UBox x; x.cx = mkf(r[0]); x.cy = mkf(r[1]); x.cz = mkf(r[2]); x.hx = mkf(r[3]); x.hy = mkf(r[4]); x.hz = mkf(r[5]); x.a = r[6]; x.b = r[7]; return x; }
 __device__ __forceinline__ UBox load_ubox(const RRT_CONSTANT void* p) { return mk_ubox(*(const RRT_CONSTANT u32x8*)p); }
 
 // One triangle held in SGPRs (wave-uniform): v1 and the two precomputed edges, plus its position in the node's own list.
@@ -269,7 +269,7 @@ __device__ __forceinline__ bool slab_from_quotients(double t1, double t2, double
 // A direction component smaller than 1e-20 is treated as parallel (inv = 1e30): over any t that matters the ray does not move along
 // that axis by more than the box padding.  Rays with non-finite or out-of-scale components (and every ray in RRT_FLAG_NO_CULL mode) get
 // inv = n = 0: all six slab values are then 0 and every box tests as hit, i.e. the filter is off for that lane.
-struct Ray32 { float ix, iy, iz, nx, ny, nz; };
+struct Ray32 { float ix, iy, iz, nx, ny, nz, ax, ay, az; };   // ax = |ix| ...
 __device__ __forceinline__ Ray32 make_ray32(V3 o, V3 d, float limit, bool enabled) {
     const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z, dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
     Ray32 r;
@@ -279,15 +279,18 @@ __device__ __forceinline__ Ray32 make_ray32(V3 o, V3 d, float limit, bool enable
     r.iy = !cull ? 0.0f : fabsf(dy) < 1e-20f ? 1e30f : __builtin_amdgcn_rcpf(dy);
     r.iz = !cull ? 0.0f : fabsf(dz) < 1e-20f ? 1e30f : __builtin_amdgcn_rcpf(dz);
     r.nx = !cull ? 0.0f : -ox * r.ix; r.ny = !cull ? 0.0f : -oy * r.iy; r.nz = !cull ? 0.0f : -oz * r.iz;
+    r.ax = fabsf(r.ix); r.ay = fabsf(r.iy); r.az = fabsf(r.iz);
     return r;
 }
-// true unless the ray (t >= 0) certainly misses the padded box; the box is wave-uniform
+// true unless the ray (t >= 0) certainly misses the padded box; the box (centre c, half-extent h) is wave-uniform.  Per axis the slab values
+// of the planes c -/+ h are  (c*inv + n) -/+ h*|inv|: the smaller one is the near plane whatever the sign of the direction.
 __device__ __forceinline__ bool slab32(const UBox& b, const Ray32& r) {
-    const float ax = __builtin_fmaf(b.lox, r.ix, r.nx), bx = __builtin_fmaf(b.hix, r.ix, r.nx);
-    const float ay = __builtin_fmaf(b.loy, r.iy, r.ny), by = __builtin_fmaf(b.hiy, r.iy, r.ny);
-    const float az = __builtin_fmaf(b.loz, r.iz, r.nz), bz = __builtin_fmaf(b.hiz, r.iz, r.nz);
-    const float tmin = fmaxf(fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)), 0.0f);
-    const float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    const float tx = __builtin_fmaf(b.cx, r.ix, r.nx), ty = __builtin_fmaf(b.cy, r.iy, r.ny), tz = __builtin_fmaf(b.cz, r.iz, r.nz);
+    const float nx = __builtin_fmaf(-b.hx, r.ax, tx), fx = __builtin_fmaf(b.hx, r.ax, tx);
+    const float ny = __builtin_fmaf(-b.hy, r.ay, ty), fy = __builtin_fmaf(b.hy, r.ay, ty);
+    const float nz = __builtin_fmaf(-b.hz, r.az, tz), fz = __builtin_fmaf(b.hz, r.az, tz);
+    const float tmin = fmaxf(fmaxf(fmaxf(nx, ny), nz), 0.0f);
+    const float tmax = fminf(fminf(fx, fy), fz);
     return tmin <= tmax;
 }
 
@@ -370,7 +373,7 @@ __device__ __forceinline__ void wave_min12_f32(float (&x)[12]) {
 // = (b - c)*inv_l + m_l with m_l = (c - o_l)*inv_l and c a common reference point (the first active lane's origin: m_l = 0 for a bundle
 // with one origin).  With inv_l in [imin, imax] (same sign) and m_l in [mmin, mmax], a_l(b) lies in (b-c)*[imin,imax] + [mmin,mmax]: an
 // interval that bounds every lane's near/far slab values, so a box whose interval test fails is missed by every lane's own test.
-struct Bundle { float cx, cy, cz, ilx, ihx, ily, ihy, ilz, ihz, mlx, mhx, mly, mhy, mlz, mhz; };
+struct Bundle { float cx, cy, cz, ilx, ihx, ily, ihy, ilz, ihz, mlx, mhx, mly, mhy, mlz, mhz, amx, amy, amz; };   // am = max |inv| over the lanes
 // The rays are anchored at their point of parameter tau: q_l = o_l + tau d_l, and (b - o_l) inv_l = (b - q_l) inv_l + tau.  tau = 0 (the origin) is
 // tight for rays that start together (a primary tile), tau = 1 for shadow rays, which end together at the light (raytracer.rs:170-174: origin + dir
 // = light + 1e-4 n): their origins are spread along the tile's view rays, their far ends are not.
@@ -400,6 +403,7 @@ __device__ __forceinline__ Bundle make_bundle(bool active, V3 o, V3 d, const Ray
     if (act == 0ull || __builtin_amdgcn_ballot_w64(active && r.ix == 0.0f && r.iy == 0.0f && r.iz == 0.0f) != 0ull) {
         B.ilx = B.ihx = B.ily = B.ihy = B.ilz = B.ihz = 0.0f; B.mlx = B.mhx = B.mly = B.mhy = B.mlz = B.mhz = 0.0f;
     }
+    B.amx = fmaxf(fabsf(B.ilx), fabsf(B.ihx)); B.amy = fmaxf(fabsf(B.ily), fabsf(B.ihy)); B.amz = fmaxf(fabsf(B.ilz), fabsf(B.ihz));
     return B;
 }
 // Is the bundle worth testing boxes against (lane-filter kernel: long own lists switch to boxes in lanes when it is)?  Every axis: directions of
@@ -421,19 +425,21 @@ __device__ __forceinline__ bool bundle_is_tight(const Bundle& B, float slack) {
 #undef RRT_TIGHT
     return ok;
 }
-// per-LANE box (lo/hi in VGPRs) against the bundle: false only if no active lane's own slab test could pass
-__device__ __forceinline__ bool bundle_hit(const Bundle& B, float lox, float loy, float loz, float hix, float hiy, float hiz) {
-#define RRT_AX(lo, hi, c, il, ih, ml, mh, tn, tf)                                                              \
+// per-LANE box (centre c, half-extent h in VGPRs) against the bundle: false only if no active lane's own slab test could pass.  For a plane
+// coordinate b = cb + s, |s| <= h, lane l's slab value is (b - c) inv_l + m_l = p inv_l + s inv_l + m_l with p = cb - c: the first term lies
+// between p*il and p*ih (linear in inv_l), the second within h*am of 0, the third in [ml, mh].
+__device__ __forceinline__ bool bundle_hit(const Bundle& B, float cx, float cy, float cz, float hx, float hy, float hz) {
+#define RRT_AX(cb, h, c, il, ih, ml, mh, am, tn, tf)                                                           \
     float tn, tf;                                                                                               \
     {                                                                                                           \
-        const float pl = lo - c, ph = hi - c;                                                                   \
-        const float a1 = pl * il, a2 = pl * ih, b1 = ph * il, b2 = ph * ih;                                     \
-        tn = fminf(fminf(a1, a2), fminf(b1, b2)) + ml;                                                          \
-        tf = fmaxf(fmaxf(a1, a2), fmaxf(b1, b2)) + mh;                                                          \
+        const float p = cb - c;                                                                                 \
+        const float a1 = p * il, a2 = p * ih;                                                                   \
+        tn = __builtin_fmaf(-h, am, fminf(a1, a2) + ml);                                                        \
+        tf = __builtin_fmaf(h, am, fmaxf(a1, a2) + mh);                                                         \
     }
-    RRT_AX(lox, hix, B.cx, B.ilx, B.ihx, B.mlx, B.mhx, tnx, tfx)
-    RRT_AX(loy, hiy, B.cy, B.ily, B.ihy, B.mly, B.mhy, tny, tfy)
-    RRT_AX(loz, hiz, B.cz, B.ilz, B.ihz, B.mlz, B.mhz, tnz, tfz)
+    RRT_AX(cx, hx, B.cx, B.ilx, B.ihx, B.mlx, B.mhx, B.amx, tnx, tfx)
+    RRT_AX(cy, hy, B.cy, B.ily, B.ihy, B.mly, B.mhy, B.amy, tny, tfy)
+    RRT_AX(cz, hz, B.cz, B.ilz, B.ihz, B.mlz, B.mhz, B.amz, tnz, tfz)
 #undef RRT_AX
     return fmaxf(fmaxf(fmaxf(tnx, tny), tnz), 0.0f) <= fminf(fminf(tfx, tfy), tfz);
 }
@@ -457,8 +463,8 @@ __device__ __forceinline__ void own_cluster_lane(PROF_DECL const RRT_CONSTANT De
     uint32_t lane_tri = 0, wave_tri = 0;
 #define RRT_TB(i, v, off)                                                                                                          \
     if (i < cn) {                                                                                                                  \
-        UBox B; B.lox = mkf(v[off]); B.loy = mkf(v[off + 1]); B.loz = mkf(v[off + 2]);                                             \
-        B.hix = mkf(v[off + 3]); B.hiy = mkf(v[off + 4]); B.hiz = mkf(v[off + 5]); B.a = 0; B.b = 0;                               \
+        UBox B; B.cx = mkf(v[off]); B.cy = mkf(v[off + 1]); B.cz = mkf(v[off + 2]);                                             \
+        B.hx = mkf(v[off + 3]); B.hy = mkf(v[off + 4]); B.hz = mkf(v[off + 5]); B.a = 0; B.b = 0;                               \
         const bool h = hc && slab32(B, r32);                                                                                      \
         PROF_ADD(4, 1);                                                                                                            \
         lane_tri |= h ? (1u << i) : 0u;                                                                                            \
@@ -580,8 +586,8 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                         const RRT_CONSTANT u32x16* cbx = (const RRT_CONSTANT u32x16*)(child_boxes + (fc - 1u));
 #define RRT_CB(k, v, off)                                                                                                          \
                         if (fl & (1u << k)) {                                                                                      \
-                            UBox B; B.lox = mkf(v[off]); B.loy = mkf(v[off + 1]); B.loz = mkf(v[off + 2]);                         \
-                            B.hix = mkf(v[off + 3]); B.hiy = mkf(v[off + 4]); B.hiz = mkf(v[off + 5]); B.a = 0; B.b = 0;           \
+                            UBox B; B.cx = mkf(v[off]); B.cy = mkf(v[off + 1]); B.cz = mkf(v[off + 2]);                         \
+                            B.hx = mkf(v[off + 3]); B.hy = mkf(v[off + 4]); B.hz = mkf(v[off + 5]); B.a = 0; B.b = 0;           \
                             const bool h = slab32(B, r32);                                                                        \
                             lane_reach |= h ? (1u << k) : 0u;                                                                      \
                             reach |= (__builtin_amdgcn_ballot_w64(h) != 0ull) ? (1u << k) : 0u;                                                          \
@@ -595,15 +601,13 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                     // (ray.rs:22-27) is formed ONCE per plane that some reachable child uses (6..9 IEEE divides per node instead of 6 per
                     // child), with the reference's operands, and each child's test is then the reference's min/max on those quotients.
                     // child k = BBL,BFL,BFR,BBR,TBL,TFL,TFR,TBR (octree.rs:216-225): upper x half for k in {2,3,6,7}, y {4..7}, z {1,2,5,6}
-                    UPlanes NP{};
                     if (reach) {
-                        uint32_t after = reach;                                                            // (an address that depends on the filter's result: the load is issued after it)
-                        asm volatile("s_and_b32 %0, %0, 0" : "+s"(after));
-                        NP = load_uplanes(nodes + unode + after, N.mid2);
-                    }
+                    uint32_t after = reach;                                                                // (an address that depends on the filter's result: the load is issued after it)
+                    asm volatile("s_and_b32 %0, %0, 0" : "+s"(after));
+                    const UPlanes NP = load_uplanes(nodes + unode + after, N.mid2);                        // (declared inside the branch: a zero-initialised NP outside it cost 16 v_writelane per visit)
                     if ((reach & (reach - 1u)) == 0u) {
                         // a single candidate child (the usual case after the reach filter): its six quotients, nothing to sort
-                        if (reach) {
+                        {
                             const uint32_t k = (uint32_t)__builtin_ctz(reach);                           // wave-uniform
                             const bool ux = (0xCCu >> k) & 1u, uy = (0xF0u >> k) & 1u, uz = (0x66u >> k) & 1u;   // upper half per axis
                             const double clx = ux ? NP.mid[0] : NP.lo[0], chx = ux ? NP.hi[0] : NP.mid[0];
@@ -704,6 +708,7 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                             if (vk[k]) { order |= (uint32_t)k << (3u * rank); nchild++; }
                         }
                     }
+                    }
 
                 }
             }
@@ -729,6 +734,7 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                 const float* q = stk.park();
                 BL.cx = q[0]; BL.cy = q[1]; BL.cz = q[2]; BL.ilx = q[3]; BL.ihx = q[4]; BL.ily = q[5]; BL.ihy = q[6]; BL.ilz = q[7]; BL.ihz = q[8];
                 BL.mlx = q[9]; BL.mhx = q[10]; BL.mly = q[11]; BL.mhy = q[12]; BL.mlz = q[13]; BL.mhz = q[14];
+                BL.amx = fmaxf(fabsf(BL.ilx), fabsf(BL.ihx)); BL.amy = fmaxf(fabsf(BL.ily), fabsf(BL.ihy)); BL.amz = fmaxf(fabsf(BL.ilz), fabsf(BL.ihz));
             }
             for (uint32_t s0 = 0; s0 < sc; s0 += 64u) {
                 uint32_t l1a = N.s0_begin, l1b = N.s0_count, n1 = 1;             // a single super-cluster: its slot range is in the node record
@@ -738,7 +744,7 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                     if (si < sc) {
                         const DevSuper* P = (const DevSuper*)supers + sb + si;
                         tb = P->tri_begin; tn = P->tri_count;
-                        h = (!kGroups || tn != 0u) && bundle_hit(BL, P->lo[0], P->lo[1], P->lo[2], P->hi[0], P->hi[1], P->hi[2]);   // (tn == 0: a group record, clusters.cpp -- the lane-filter kernel's business)
+                        h = (!kGroups || tn != 0u) && bundle_hit(BL, P->c[0], P->c[1], P->c[2], P->h[0], P->h[1], P->h[2]);   // (tn == 0: a group record, clusters.cpp -- the lane-filter kernel's business)
                     }
                     PROF_ADD(10, 1);
                     n1 = wave_compact2(h, tb, tn, lane, l1a, l1b);
@@ -749,7 +755,7 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                     bool h2 = false;
                     if (e < n1 && sub * 8u < etn) {
                         const DevClusterBox* P = (const DevClusterBox*)cboxes + (etb >> 3) + sub;
-                        h2 = bundle_hit(BL, P->lo[0], P->lo[1], P->lo[2], P->hi[0], P->hi[1], P->hi[2]);
+                        h2 = bundle_hit(BL, P->c[0], P->c[1], P->c[2], P->h[0], P->h[1], P->h[2]);
                     }
                     PROF_ADD(11, 1);
                     uint32_t l2a, l2b;
@@ -760,7 +766,7 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                         bool h3 = false;
                         if (f < n2 && sub < fn) {
                             const DevClusterBox* P = (const DevClusterBox*)tboxes + fs + sub;
-                            h3 = bundle_hit(BL, P->lo[0], P->lo[1], P->lo[2], P->hi[0], P->hi[1], P->hi[2]);
+                            h3 = bundle_hit(BL, P->c[0], P->c[1], P->c[2], P->h[0], P->h[1], P->h[2]);
                         }
                         PROF_ADD(4, 1);
                         uint32_t l3a, l3b;
@@ -785,7 +791,7 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
         if (mine && (fl & 0x100u)) {
                 if (sc) {
                 // a node with a single super-cluster carries its slot range in the node record and skips the super-cluster box
-                UBox SP; SP.a = N.s0_begin; SP.b = N.s0_count; SP.lox = SP.loy = SP.loz = SP.hix = SP.hiy = SP.hiz = 0.0f;
+                UBox SP; SP.a = N.s0_begin; SP.b = N.s0_count; SP.cx = SP.cy = SP.cz = SP.hx = SP.hy = SP.hz = 0.0f;
                 if (sc > 1) SP = load_ubox(supers + sb);
                 for (uint32_t si = 0; si < sc; ++si) {
                     UBox SN = SP;
@@ -811,8 +817,8 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                         uint32_t lane_hits = 0, wave_hits = 0;
 #define RRT_CL(c, v, off)                                                                                                          \
                         if (c < nc) {                                                                                          \
-                            UBox B; B.lox = mkf(v[off]); B.loy = mkf(v[off + 1]); B.loz = mkf(v[off + 2]);                     \
-                            B.hix = mkf(v[off + 3]); B.hiy = mkf(v[off + 4]); B.hiz = mkf(v[off + 5]); B.a = 0; B.b = 0;       \
+                            UBox B; B.cx = mkf(v[off]); B.cy = mkf(v[off + 1]); B.cz = mkf(v[off + 2]);                     \
+                            B.hx = mkf(v[off + 3]); B.hy = mkf(v[off + 4]); B.hz = mkf(v[off + 5]); B.a = 0; B.b = 0;       \
                             const bool h = hs && slab32(B, r32);                                                              \
                             PROF_ADD(11, 1);                                                                                   \
                             lane_hits |= h ? (1u << c) : 0u;                                                                   \
