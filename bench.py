@@ -86,6 +86,7 @@ def main() -> None:
                     "gather and de-tiling behind the C ABI); `torch` = the same choreography issued from here with torch.distributed.gather; `auto` = K steps of each, "
                     "torch first, the library under a watchdog, the faster one reported (both in `gather_paths`)")
     ap.add_argument("--lib-timeout", type=float, default=120.0, help="--gather auto: seconds the library path may take before the torch result is reported alone")
+    ap.add_argument("--walk", choices=("auto", "lane", "bundle", "ray"), default="auto", help="traversal variant: auto = the library measures all three on the first frame (the product default); the others force one (developer A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-fb", action="store_true", help="skip the boundary-inclusive rrt_render timings (frame_ms_host_fb)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the bounded cpu_baseline leg (3 samples)")
@@ -140,7 +141,7 @@ def main() -> None:
     t_setup = time.perf_counter()
     sd = rrt.parse_obj_file(args.scene)
     lights = rrt.default_lights()
-    rt = rrt.RayTracer(sd, lights, rrt.DEFAULT_ORIGIN, device=local_rank)
+    rt = rrt.RayTracer(sd, lights, rrt.DEFAULT_ORIGIN, device=local_rank, box_filter=None if args.walk == "auto" else args.walk)
     setup_wall_ms = (time.perf_counter() - t_setup) * 1e3
     setup = {k: round(v, 2) for k, v in rt.setup_times().items()}
     setup["total_ms"] = round(sum(setup.values()), 2); setup["wall_ms_incl_binding"] = round(setup_wall_ms, 2)
@@ -463,7 +464,7 @@ def main() -> None:
                "config": {"workload": f"{scene_name} {W}x{H}, 4 sub-samples/pixel, shadow rays + depth-5 mirror reflection, f64",
                           "rays_primary_per_frame": rays_primary,
                           "partition": "single launch" if not multi else f"8x8-pixel tiles round-robin over {world} GPUs + RCCL gather to GPU 0, " + (f"inside the library (rrt_multi_enqueue), {DEPTH} frames in flight" if in_lib else "torch.distributed.gather, " + ("one frame at a time" if simple[0] else f"{DEPTH} frames in flight (one stream per slot)")),
-                          "octree_nodes": sd.info["n_nodes"], "triangles": sd.info["n_tris"], "filter_variant": "bundle" if rt.last_stats()["filter_variant"] else "lane"},
+                          "octree_nodes": sd.info["n_nodes"], "triangles": sd.info["n_tris"], "filter_variant": rrt.VARIANT_NAMES[rt.last_stats()["filter_variant"]]},
                "frame_ms": round(ms_per_step, 4), "kernel_ms": round(kernel_ms, 4), "host_enqueue_ms_per_step": round(host_enqueue_ms, 4), "setup_ms": setup,
                **({"rehearsal": "gloo on one GPU: NOT a benchmark result"} if rehearsal else {}),
                "frame_checksum": int(np.bitwise_xor.reduce(frame.ravel().astype(np.uint64) * np.arange(1, frame.size + 1, dtype=np.uint64)))}

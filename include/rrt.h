@@ -61,6 +61,10 @@ typedef struct { const uint8_t *rgb; uint32_t width, height; } rrt_texture;
  * every new frame size is rendered with both (a one-off stream synchronisation) and the faster is kept for that size; these flags force one. */
 #define RRT_FLAG_LANE_FILTER 2u
 #define RRT_FLAG_BUNDLE_FILTER 4u
+/* Both of the above walk the octree node-coherently (one node per wave step, records in scalar registers): right for rays that share nodes.
+ * RAY_WALK lets every ray of a wave visit its own node in every step (records through vector memory): right for scattered rays (large soups,
+ * mirror bounces).  Same pixels again; the default measures all three on the first frame of a size. */
+#define RRT_FLAG_RAY_WALK 8u
 
 /* Render constants that the reference hard-codes; NULL => these defaults. */
 typedef struct {
@@ -82,7 +86,7 @@ typedef struct {
     uint32_t width, height;
     uint64_t rays_primary;            /* 4 * pixels actually traced */
     uint64_t scene_bytes;             /* bytes resident in HBM for this raytracer (geometry+octree+textures) */
-    uint32_t filter_variant;          /* 0 = LANE filter, 1 = BUNDLE filter (forced, or measured on the first frame of this size) */
+    uint32_t filter_variant;          /* 0 = LANE filter, 1 = BUNDLE filter, 2 = RAY walk (forced, or measured on the first frame of this size) */
     uint32_t origin_plane_triangles;  /* triangles whose plane contains the raytracer's origin to rounding distance: rays from the origin that lie
                                        * in such a plane run with the index filters off (exactness guard); 0 for ordinary scenes */
 } rrt_stats;

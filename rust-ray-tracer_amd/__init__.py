@@ -31,7 +31,8 @@ class RrtError(RuntimeError):
         self.detail = detail
 
 
-FLAG_NO_CULL, FLAG_LANE_FILTER, FLAG_BUNDLE_FILTER = 1, 2, 4   # RRT_FLAG_*, include/rrt.h
+FLAG_NO_CULL, FLAG_LANE_FILTER, FLAG_BUNDLE_FILTER, FLAG_RAY_WALK = 1, 2, 4, 8   # RRT_FLAG_*, include/rrt.h
+VARIANT_NAMES = ("lane", "bundle", "ray")   # rrt_stats.filter_variant
 
 # status codes, include/rrt.h
 OK, ERR_INVALID_ARG, ERR_HIP, ERR_OOM, ERR_IO, ERR_PARSE, ERR_DEPTH, ERR_NO_DEVICE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7, -8
@@ -279,12 +280,13 @@ class RayTracer:
                  surface_offset: float = 0.0001, max_reflection_depth: int = 5, viewport=(1.0, 1.0, 1.0), no_cull: bool = False,
                  box_filter: Optional[str] = None):
         """no_cull=True (RRT_FLAG_NO_CULL): walk every own list in full, in list order, as ray.rs:119-129; default uses the cluster boxes.
-        box_filter: None = measured at create, "lane" / "bundle" = forced (RRT_FLAG_LANE_FILTER / RRT_FLAG_BUNDLE_FILTER); same pixels."""
+        box_filter: None = measured on the first frame, "lane" / "bundle" / "ray" = forced (RRT_FLAG_LANE_FILTER / RRT_FLAG_BUNDLE_FILTER /
+        RRT_FLAG_RAY_WALK); same pixels."""
         self.scene_data, self.lights, self.origin, self.device = scene_data, list(lights), origin, device
         cl = (CLight * max(1, len(self.lights)))()
         for i, l in enumerate(self.lights):
             cl[i] = CLight(l.kind, 0, float(l.intensity), l.v._c())
-        flags = (FLAG_NO_CULL if no_cull else 0) | {None: 0, "lane": FLAG_LANE_FILTER, "bundle": FLAG_BUNDLE_FILTER}[box_filter]
+        flags = (FLAG_NO_CULL if no_cull else 0) | {None: 0, "lane": FLAG_LANE_FILTER, "bundle": FLAG_BUNDLE_FILTER, "ray": FLAG_RAY_WALK}[box_filter]
         opt = COptions(surface_offset, max_reflection_depth, flags, *map(float, viewport))
         out = _P()
         _check(lib().rrt_raytracer_create(scene_data._h, cl, len(self.lights), origin._c(), C.byref(opt), device, C.byref(out)), "rrt_raytracer_create")

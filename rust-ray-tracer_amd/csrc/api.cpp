@@ -29,7 +29,9 @@ struct rrt_raytracer {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     rrt_stats stats{};
     bool stats_pending = false;
-    bool bundle = false;             // own-list filter variant used by this raytracer's launches (see rrt.h)
+    bool launched = false;           // some launch has been recorded in `stats`
+    int walk = 0;                    // traversal variant used by this raytracer's frame launches: 0 lane filter, 1 bundle filter, 2 ray walk (see rrt.h)
+    int walk_rays = -1;              // ... and by its per-ray entry points (rrt_get_ray_colours / rrt_intersect_rays): -1 = not measured yet (tune_rays_variant)
     bool variant_forced = false;
     void* host_fb = nullptr;         // device framebuffer kept between rrt_render calls (host-buffer entry point)
     size_t host_fb_bytes = 0;
@@ -161,12 +163,13 @@ void check_frame(const rrt_raytracer* rt, uint32_t width, uint32_t height) {
 // stream, timed with HIP events, and the faster one is kept for that size.  This synchronises the stream once per new size.
 void tune_variant(rrt_raytracer* rt, const FrameParams& f, uint32_t* d_out, void* stream) {
     if (rt->variant_forced || (rt->tuned_w == f.width && rt->tuned_h == f.height && rt->tuned_world == f.world)) return;
-    float ms[2] = {0, 0};
+    constexpr int kVariants = 3;
+    float ms[kVariants] = {0, 0, 0};
     if (f.world == 1) {
-        for (int variant = 0; variant < 2; variant++)
+        for (int variant = 0; variant < kVariants; variant++)
             for (int rep = 0; rep < 2; rep++) {
                 HIP_TRY(hipEventRecord(rt->ev0, (hipStream_t)stream));
-                HIP_TRY((hipError_t)launch_render(rt->scene, f, d_out, stream, variant == 1));
+                HIP_TRY((hipError_t)launch_render(rt->scene, f, d_out, stream, variant));
                 HIP_TRY(hipEventRecord(rt->ev1, (hipStream_t)stream));
                 HIP_TRY(hipEventSynchronize(rt->ev1));
                 HIP_TRY(hipEventElapsedTime(&ms[variant], rt->ev0, rt->ev1));
@@ -179,19 +182,52 @@ void tune_variant(rrt_raytracer* rt, const FrameParams& f, uint32_t* d_out, void
         hipStream_t st[3] = {nullptr, nullptr, nullptr};
         struct Cleanup { hipStream_t* s; ~Cleanup() { for (int i = 0; i < 3; i++) if (s[i]) (void)hipStreamDestroy(s[i]); } } cl{st};
         for (auto& q : st) HIP_TRY(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
-        for (int variant = 0; variant < 2; variant++)
+        for (int variant = 0; variant < kVariants; variant++)
             for (int rep = 0; rep < 2; rep++) {                           // rep 0 warms up
                 HIP_TRY(hipEventRecord(rt->ev0, st[0]));
                 for (int round = 0; round < 2; round++)
-                    for (auto q : st) HIP_TRY((hipError_t)launch_render(rt->scene, f, d_out, q, variant == 1));   // same pixels from every launch: the overlapping writes agree
+                    for (auto q : st) HIP_TRY((hipError_t)launch_render(rt->scene, f, d_out, q, variant));   // same pixels from every launch: the overlapping writes agree
                 for (int i = 1; i < 3; i++) HIP_TRY(hipStreamSynchronize(st[i]));
                 HIP_TRY(hipEventRecord(rt->ev1, st[0]));
                 HIP_TRY(hipEventSynchronize(rt->ev1));
                 HIP_TRY(hipEventElapsedTime(&ms[variant], rt->ev0, rt->ev1));
             }
     }
-    rt->bundle = ms[1] < ms[0];
+    rt->walk = 0;
+    for (int variant = 1; variant < kVariants; variant++) if (ms[variant] < ms[rt->walk]) rt->walk = variant;
     rt->tuned_w = f.width; rt->tuned_h = f.height; rt->tuned_world = f.world;
+}
+
+// The per-ray entry points take whatever rays the caller has: a coherent pixel grid or rays in all directions, and the three traversal variants are
+// up to 5x apart on those (scattered rays: the ray walk; tools/random_rays_probe.py).  The first batch of at least kTuneMinRays rays is therefore
+// used to measure them on its first kTuneSample rays (each twice, the first run warms caches; same outputs from every variant), and the fastest is
+// kept for later calls.  A forced variant (RRT_FLAG_*_FILTER / RAY_WALK / NO_CULL) is used as is; smaller batches run the frame variant.
+constexpr uint32_t kTuneMinRays = 16384, kTuneSample = 65536;
+template <class Launch> int rays_variant(rrt_raytracer* rt, uint32_t n, Launch&& launch) {
+    if (rt->variant_forced) return rt->walk;
+    if (rt->walk_rays >= 0) return rt->walk_rays;
+    if (n < kTuneMinRays) return rt->walk;
+    const uint32_t m = n < kTuneSample ? n : kTuneSample;
+    float best = 0; int best_v = 0;
+    for (int variant = 0; variant < 3; variant++) {
+        float ms = 0;
+        for (int rep = 0; rep < 2; rep++) {
+            HIP_TRY(hipEventRecord(rt->ev0, nullptr));
+            HIP_TRY((hipError_t)launch(m, variant));
+            HIP_TRY(hipEventRecord(rt->ev1, nullptr));
+            HIP_TRY(hipEventSynchronize(rt->ev1));
+            HIP_TRY(hipEventElapsedTime(&ms, rt->ev0, rt->ev1));
+        }
+        if (variant == 0 || ms < best) { best = ms; best_v = variant; }
+    }
+    rt->walk_rays = best_v;
+    return best_v;
+}
+// (kernel time of a per-ray launch into rrt_stats, like a frame's)
+void record_rays(rrt_raytracer* rt, uint32_t n, int variant) {
+    rt->stats.width = n; rt->stats.height = 1; rt->stats.rays_primary = n;
+    rt->stats.scene_bytes = rt->scene_bytes; rt->stats.filter_variant = (uint32_t)variant; rt->stats.origin_plane_triangles = rt->n_suspects;
+    rt->stats_pending = true; rt->launched = true;
 }
 
 void record_launch(rrt_raytracer* rt, uint32_t width, uint32_t height, uint32_t rank, uint32_t world) {
@@ -200,8 +236,8 @@ void record_launch(rrt_raytracer* rt, uint32_t width, uint32_t height, uint32_t 
     rt->stats.rays_primary = world == 1 ? 4ull * wt * ht : 0;   // per-rank share is not tracked
     (void)rank;
     rt->stats.scene_bytes = rt->scene_bytes;
-    rt->stats.filter_variant = rt->bundle ? 1u : 0u; rt->stats.origin_plane_triangles = rt->n_suspects;
-    rt->stats_pending = true;
+    rt->stats.filter_variant = (uint32_t)rt->walk; rt->stats.origin_plane_triangles = rt->n_suspects;
+    rt->stats_pending = true; rt->launched = true;
 }
 
 }  // namespace
@@ -503,8 +539,8 @@ int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n
         rt->index_ms = std::chrono::duration<double, std::milli>(t_index1 - t_index0).count();
         rt->upload_ms = std::chrono::duration<double, std::milli>(clk::now() - t_index1).count();
         // Own-list filter variant: forced by a flag, else measured on the first frame of each frame size (tune_variant below)
-        rt->variant_forced = (o.flags & (RRT_FLAG_BUNDLE_FILTER | RRT_FLAG_LANE_FILTER | RRT_FLAG_NO_CULL)) != 0;
-        rt->bundle = (o.flags & RRT_FLAG_BUNDLE_FILTER) != 0 && !(o.flags & RRT_FLAG_NO_CULL);
+        rt->variant_forced = (o.flags & (RRT_FLAG_BUNDLE_FILTER | RRT_FLAG_LANE_FILTER | RRT_FLAG_RAY_WALK | RRT_FLAG_NO_CULL)) != 0;
+        rt->walk = (o.flags & RRT_FLAG_NO_CULL) ? 0 : (o.flags & RRT_FLAG_BUNDLE_FILTER) ? 1 : (o.flags & RRT_FLAG_RAY_WALK) ? 2 : 0;
         *out = rt.release();
         return RRT_OK;
     });
@@ -541,7 +577,7 @@ int rrt_render_tiles_device(rrt_raytracer* rt, uint32_t width, uint32_t height, 
         const FrameParams f = frame_params(rt, width, height, rank, world, true);
         tune_variant(rt, f, static_cast<uint32_t*>(d_tiles), stream);
         HIP_TRY(hipEventRecord(rt->ev0, (hipStream_t)stream));
-        HIP_TRY((hipError_t)launch_render(rt->scene, f, static_cast<uint32_t*>(d_tiles), stream, rt->bundle));
+        HIP_TRY((hipError_t)launch_render(rt->scene, f, static_cast<uint32_t*>(d_tiles), stream, rt->walk));
         HIP_TRY(hipEventRecord(rt->ev1, (hipStream_t)stream));
         record_launch(rt, width, height, rank, world);
         return RRT_OK;
@@ -556,7 +592,7 @@ int rrt_render_device(rrt_raytracer* rt, uint32_t width, uint32_t height, void* 
         const FrameParams f = frame_params(rt, width, height, 0, 1, false);
         tune_variant(rt, f, static_cast<uint32_t*>(d_fb), stream);
         HIP_TRY(hipEventRecord(rt->ev0, (hipStream_t)stream));
-        HIP_TRY((hipError_t)launch_render(rt->scene, f, static_cast<uint32_t*>(d_fb), stream, rt->bundle));
+        HIP_TRY((hipError_t)launch_render(rt->scene, f, static_cast<uint32_t*>(d_fb), stream, rt->walk));
         HIP_TRY(hipEventRecord(rt->ev1, (hipStream_t)stream));
         record_launch(rt, width, height, 0, 1);
         return RRT_OK;
@@ -665,7 +701,7 @@ int rrt_render_progressive(rrt_raytracer* rt, uint32_t width, uint32_t height, u
             if (r_lo <= r_hi) {
                 f.row_begin = (uint32_t)r_lo; f.row_end = (uint32_t)r_hi + 1;
                 f.tile_begin = (f.row_begin / 8) * f.tiles_x; f.tile_end = ((f.row_end + 7) / 8) * f.tiles_x;
-                HIP_TRY((hipError_t)launch_render(rt->scene, f, d_fb, nullptr, rt->bundle));
+                HIP_TRY((hipError_t)launch_render(rt->scene, f, d_fb, nullptr, rt->walk));
                 HIP_TRY(hipMemcpy(out_fb + (size_t)f.row_begin * width, d_fb + (size_t)f.row_begin * width,
                                   sizeof(uint32_t) * (size_t)width * (f.row_end - f.row_begin), hipMemcpyDeviceToHost));
             }
@@ -687,7 +723,11 @@ int rrt_get_ray_colours(rrt_raytracer* rt, uint32_t n, const double* origins, co
         HIP_TRY(hipMalloc((void**)&d_o, sizeof(double) * 3 * (size_t)n)); HIP_TRY(hipMalloc((void**)&d_d, sizeof(double) * 3 * (size_t)n)); HIP_TRY(hipMalloc((void**)&d_c, sizeof(uint32_t) * (size_t)n));
         HIP_TRY(hipMemcpy(d_o, origins, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d_d, dirs, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice));
-        HIP_TRY((hipError_t)launch_ray_colours(rt->scene, n, d_o, d_d, d_c, nullptr, rt->bundle));
+        const int variant = rays_variant(rt, n, [&](uint32_t m, int v) { return launch_ray_colours(rt->scene, m, d_o, d_d, d_c, nullptr, v); });
+        HIP_TRY(hipEventRecord(rt->ev0, nullptr));
+        HIP_TRY((hipError_t)launch_ray_colours(rt->scene, n, d_o, d_d, d_c, nullptr, variant));
+        HIP_TRY(hipEventRecord(rt->ev1, nullptr));
+        record_rays(rt, n, variant);
         HIP_TRY(hipMemcpy(colours, d_c, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost));
         return (int)RRT_OK;
     });
@@ -707,8 +747,15 @@ int rrt_intersect_rays(rrt_raytracer* rt, uint32_t n, const double* origins, con
         HIP_TRY(hipMemcpy(bufs[0], origins, 24 * N, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(bufs[1], dirs, 24 * N, hipMemcpyHostToDevice));
         if (max_t) HIP_TRY(hipMemcpy(bufs[2], max_t, 8 * N, hipMemcpyHostToDevice));
-        HIP_TRY((hipError_t)launch_intersect(rt->scene, n, (const double*)bufs[0], (const double*)bufs[1], max_t ? (const double*)bufs[2] : nullptr,
-                                             (uint8_t*)bufs[3], (double*)bufs[4], (double*)bufs[5], (double*)bufs[6], (uint32_t*)bufs[7], nullptr, rt->bundle));
+        auto launch = [&](uint32_t m, int v) {
+            return launch_intersect(rt->scene, m, (const double*)bufs[0], (const double*)bufs[1], max_t ? (const double*)bufs[2] : nullptr,
+                                    (uint8_t*)bufs[3], (double*)bufs[4], (double*)bufs[5], (double*)bufs[6], (uint32_t*)bufs[7], nullptr, v);
+        };
+        const int variant = rays_variant(rt, n, launch);
+        HIP_TRY(hipEventRecord(rt->ev0, nullptr));
+        HIP_TRY((hipError_t)launch(n, variant));
+        HIP_TRY(hipEventRecord(rt->ev1, nullptr));
+        record_rays(rt, n, variant);
         HIP_TRY(hipMemcpy(hit, bufs[3], N, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(t, bufs[4], 8 * N, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(u, bufs[5], 8 * N, hipMemcpyDeviceToHost));
@@ -1039,7 +1086,8 @@ int rrt_last_stats(const rrt_raytracer* rt_c, rrt_stats* out) {
             rt->stats.kernel_ms = ms;
             rt->stats_pending = false;
         }
-        rt->stats.filter_variant = rt->bundle ? 1u : 0u; rt->stats.origin_plane_triangles = rt->n_suspects; rt->stats.scene_bytes = rt->scene_bytes;
+        if (!rt->launched) rt->stats.filter_variant = (uint32_t)rt->walk;   // (before the first launch: the forced variant, or 0)
+        rt->stats.origin_plane_triangles = rt->n_suspects; rt->stats.scene_bytes = rt->scene_bytes;
         *out = rt->stats;
         return RRT_OK;
     });

@@ -103,11 +103,12 @@ struct FrameParams {
 };
 
 // kernel launches (render.hip).  All return hipError_t cast to int; stream is a hipStream_t.
-int launch_render(const DevScene& s, const FrameParams& f, uint32_t* d_out, void* stream, bool bundle);
+// walk: 0 = node-coherent walk with the lane filter, 1 = node-coherent walk with the bundle filter, 2 = ray walk (render.hip)
+int launch_render(const DevScene& s, const FrameParams& f, uint32_t* d_out, void* stream, int walk);
 int launch_detile(uint32_t width, uint32_t height, uint32_t world, const uint32_t* d_gathered, uint32_t* d_fb, void* stream);
-int launch_ray_colours(const DevScene& s, uint32_t n, const double* d_origins, const double* d_dirs, uint32_t* d_colours, void* stream, bool bundle);
+int launch_ray_colours(const DevScene& s, uint32_t n, const double* d_origins, const double* d_dirs, uint32_t* d_colours, void* stream, int walk);
 int launch_intersect(const DevScene& s, uint32_t n, const double* d_origins, const double* d_dirs, const double* d_max_t,
-                     uint8_t* d_hit, double* d_t, double* d_u, double* d_v, uint32_t* d_tri, void* stream, bool bundle);
+                     uint8_t* d_hit, double* d_t, double* d_u, double* d_v, uint32_t* d_tri, void* stream, int walk);
 uint32_t stack_bytes_per_wave(uint32_t levels);
 void preload_kernels();
 

@@ -604,24 +604,30 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                     if (reach) {
                     uint32_t after = reach;                                                                // (an address that depends on the filter's result: the load is issued after it)
                     asm volatile("s_and_b32 %0, %0, 0" : "+s"(after));
-                    const UPlanes NP = load_uplanes(nodes + unode + after, N.mid2);                        // (declared inside the branch: a zero-initialised NP outside it cost 16 v_writelane per visit)
+                    const RRT_CONSTANT char* rec = (const RRT_CONSTANT char*)(nodes + unode + after);
+                    // The planes are subtracted from the origin IN THE BLOCK THAT LOADS THEM (the empty asm pins the differences there): left to
+                    // itself the compiler keeps the planes in SGPRs across the branches below, runs out of SGPRs and moves all sixteen through VGPR lanes
+                    // (16 v_writelane + 16..18 v_readlane per visit, a third of the kernel's spill traffic).
                     if ((reach & (reach - 1u)) == 0u) {
-                        // a single candidate child (the usual case after the reach filter): its six quotients, nothing to sort
+                        // a single candidate child (the usual case after the reach filter): its six planes only, fetched by offset
+                        // (DevNode: lo[a] at 8a, hi[a] at 24 + 8a, mid[a] at 48 + 8a), its six quotients, nothing to sort
                         {
                             const uint32_t k = (uint32_t)__builtin_ctz(reach);                           // wave-uniform
                             const bool ux = (0xCCu >> k) & 1u, uy = (0xF0u >> k) & 1u, uz = (0x66u >> k) & 1u;   // upper half per axis
-                            const double clx = ux ? NP.mid[0] : NP.lo[0], chx = ux ? NP.hi[0] : NP.mid[0];
-                            const double cly = uy ? NP.mid[1] : NP.lo[1], chy = uy ? NP.hi[1] : NP.mid[1];
-                            const double clz = uz ? NP.mid[2] : NP.lo[2], chz = uz ? NP.hi[2] : NP.mid[2];
+                            const double clx = *(const RRT_CONSTANT double*)(rec + (ux ? 48u : 0u)), chx = *(const RRT_CONSTANT double*)(rec + (ux ? 24u : 48u));
+                            const double cly = *(const RRT_CONSTANT double*)(rec + (uy ? 56u : 8u)), chy = *(const RRT_CONSTANT double*)(rec + (uy ? 32u : 56u));
+                            const double clz = *(const RRT_CONSTANT double*)(rec + (uz ? 64u : 16u)), chz = *(const RRT_CONSTANT double*)(rec + (uz ? 40u : 64u));
+                            double n1 = clx - o.x, n2 = chx - o.x, n3 = cly - o.y, n4 = chy - o.y, n5 = clz - o.z, n6 = chz - o.z;
+                            asm volatile("" : "+v"(n1), "+v"(n2), "+v"(n3), "+v"(n4), "+v"(n5), "+v"(n6));
                             double t = kInf;
                             PROF_ADD(8, 1); PROF_ADD(9, __popcll(__ballot(1)));
                             if (lane_reach) {
                                 double t1, t2, t3, t4, t5, t6;
                                 if (RR.plain) {
-                                    t1 = quot(clx - o.x, d.x, RR.rx); t2 = quot(chx - o.x, d.x, RR.rx); t3 = quot(cly - o.y, d.y, RR.ry);
-                                    t4 = quot(chy - o.y, d.y, RR.ry); t5 = quot(clz - o.z, d.z, RR.rz); t6 = quot(chz - o.z, d.z, RR.rz);
+                                    t1 = quot(n1, d.x, RR.rx); t2 = quot(n2, d.x, RR.rx); t3 = quot(n3, d.y, RR.ry);
+                                    t4 = quot(n4, d.y, RR.ry); t5 = quot(n5, d.z, RR.rz); t6 = quot(n6, d.z, RR.rz);
                                 } else {
-                                    t1 = (clx - o.x) / d.x; t2 = (chx - o.x) / d.x; t3 = (cly - o.y) / d.y; t4 = (chy - o.y) / d.y; t5 = (clz - o.z) / d.z; t6 = (chz - o.z) / d.z;
+                                    t1 = n1 / d.x; t2 = n2 / d.x; t3 = n3 / d.y; t4 = n4 / d.y; t5 = n5 / d.z; t6 = n6 / d.z;
                                 }
                                 if (slab_from_quotients(t1, t2, t3, t4, t5, t6, t)) { order = k; nchild = 1u; }
                             }
@@ -634,23 +640,27 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                             }
                         }
                     } else {
+                    const UPlanes NP = load_uplanes((const RRT_CONSTANT DevNode*)rec, N.mid2);
+                    double dlx = NP.lo[0] - o.x, dmx = NP.mid[0] - o.x, dhx = NP.hi[0] - o.x, dly = NP.lo[1] - o.y, dmy = NP.mid[1] - o.y, dhy = NP.hi[1] - o.y,
+                           dlz = NP.lo[2] - o.z, dmz = NP.mid[2] - o.z, dhz = NP.hi[2] - o.z;
+                    asm volatile("" : "+v"(dlx), "+v"(dmx), "+v"(dhx), "+v"(dly), "+v"(dmy), "+v"(dhy), "+v"(dlz), "+v"(dmz), "+v"(dhz));
                     double qlx = 0, qmx = 0, qhx = 0, qly = 0, qmy = 0, qhy = 0, qlz = 0, qmz = 0, qhz = 0;
                         if (RR.plain) {
-                            qmx = quot(NP.mid[0] - o.x, d.x, RR.rx); qmy = quot(NP.mid[1] - o.y, d.y, RR.ry); qmz = quot(NP.mid[2] - o.z, d.z, RR.rz);
-                            if (reach & 0x33u) qlx = quot(NP.lo[0] - o.x, d.x, RR.rx);
-                            if (reach & 0xCCu) qhx = quot(NP.hi[0] - o.x, d.x, RR.rx);
-                            if (reach & 0x0Fu) qly = quot(NP.lo[1] - o.y, d.y, RR.ry);
-                            if (reach & 0xF0u) qhy = quot(NP.hi[1] - o.y, d.y, RR.ry);
-                            if (reach & 0x99u) qlz = quot(NP.lo[2] - o.z, d.z, RR.rz);
-                            if (reach & 0x66u) qhz = quot(NP.hi[2] - o.z, d.z, RR.rz);
+                            qmx = quot(dmx, d.x, RR.rx); qmy = quot(dmy, d.y, RR.ry); qmz = quot(dmz, d.z, RR.rz);
+                            if (reach & 0x33u) qlx = quot(dlx, d.x, RR.rx);
+                            if (reach & 0xCCu) qhx = quot(dhx, d.x, RR.rx);
+                            if (reach & 0x0Fu) qly = quot(dly, d.y, RR.ry);
+                            if (reach & 0xF0u) qhy = quot(dhy, d.y, RR.ry);
+                            if (reach & 0x99u) qlz = quot(dlz, d.z, RR.rz);
+                            if (reach & 0x66u) qhz = quot(dhz, d.z, RR.rz);
                         } else {
-                            qmx = (NP.mid[0] - o.x) / d.x; qmy = (NP.mid[1] - o.y) / d.y; qmz = (NP.mid[2] - o.z) / d.z;
-                            if (reach & 0x33u) qlx = (NP.lo[0] - o.x) / d.x;
-                            if (reach & 0xCCu) qhx = (NP.hi[0] - o.x) / d.x;
-                            if (reach & 0x0Fu) qly = (NP.lo[1] - o.y) / d.y;
-                            if (reach & 0xF0u) qhy = (NP.hi[1] - o.y) / d.y;
-                            if (reach & 0x99u) qlz = (NP.lo[2] - o.z) / d.z;
-                            if (reach & 0x66u) qhz = (NP.hi[2] - o.z) / d.z;
+                            qmx = dmx / d.x; qmy = dmy / d.y; qmz = dmz / d.z;
+                            if (reach & 0x33u) qlx = dlx / d.x;
+                            if (reach & 0xCCu) qhx = dhx / d.x;
+                            if (reach & 0x0Fu) qly = dly / d.y;
+                            if (reach & 0xF0u) qhy = dhy / d.y;
+                            if (reach & 0x99u) qlz = dlz / d.z;
+                            if (reach & 0x66u) qhz = dhz / d.z;
                         }
                         double tk[8]; bool vk[8];
 #pragma unroll
@@ -900,6 +910,223 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
     out_t = ret_t; out_slot = ret_slot;
 }
 
+// ------------------------------------------------------------------------------------------------ traversal, one node per LANE (ray walk)
+// The walk above keeps the wave together: one node per step, processed by the lanes parked at it, its records in SGPRs.  That is the right shape
+// while the rays of a wave share nodes (a teapot frame: 93 % of the lanes take part in a visit) and the wrong one once they scatter -- on the
+// triangle soups half the visits serve fewer than 8 lanes and every visit costs about a thousand wave instructions whoever takes part.  Here every
+// pending lane visits ITS OWN node in every step: records come through vector memory (per-lane addresses), every test is per lane, the control
+// flow diverges only in loop trip counts.  Same index, same arithmetic, same results (the per-lane state -- cur, sp, the LDS stack frames -- is
+// the same as above; only `which lanes process which node when` differs, and no lane's result depends on another lane).
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ UHead load_lhead(const DevNode* nodes, uint32_t id) {
+    const u32x4* p = (const u32x4*)((const char*)nodes + (size_t)id * sizeof(DevNode) + 64);
+    const u32x4 a = p[0], b = p[1];
+    UHead n;
+    n.mid2 = mkd(a[0], a[1]); n.first_child = a[2]; n.sup_begin = a[3]; n.sup_count = b[0]; n.flags = b[1]; n.s0_begin = b[2]; n.s0_count = b[1] >> 24; n.leaf_base = b[3];
+    return n;
+}
+__device__ __forceinline__ UPlanes load_lplanes(const DevNode* nodes, uint32_t id, double mid2) {
+    const u32x4* q = (const u32x4*)((const char*)nodes + (size_t)id * sizeof(DevNode));
+    const u32x4 a = q[0], b = q[1], c = q[2], d = q[3];
+    UPlanes n;
+    n.lo[0] = mkd(a[0], a[1]); n.lo[1] = mkd(a[2], a[3]); n.lo[2] = mkd(b[0], b[1]);
+    n.hi[0] = mkd(b[2], b[3]); n.hi[1] = mkd(c[0], c[1]); n.hi[2] = mkd(c[2], c[3]);
+    n.mid[0] = mkd(d[0], d[1]); n.mid[1] = mkd(d[2], d[3]); n.mid[2] = mid2;
+    return n;
+}
+__device__ __forceinline__ UBox load_lbox6(const void* rec) {      // centre and half-extent only (24 of the record's 32 bytes)
+    const u32x4 a = *(const u32x4*)rec; const u32x2 b = *(const u32x2*)((const char*)rec + 16);
+    UBox x; x.cx = mkf(a[0]); x.cy = mkf(a[1]); x.cz = mkf(a[2]); x.hx = mkf(a[3]); x.hy = mkf(b[0]); x.hz = mkf(b[1]); x.a = 0; x.b = 0;
+    return x;
+}
+__device__ __forceinline__ UBox load_lbox8(const void* rec) {
+    const u32x4 a = *(const u32x4*)rec, b = *(const u32x4*)((const char*)rec + 16);
+    UBox x; x.cx = mkf(a[0]); x.cy = mkf(a[1]); x.cz = mkf(a[2]); x.hx = mkf(a[3]); x.hy = mkf(b[0]); x.hz = mkf(b[1]); x.a = b[2]; x.b = b[3];
+    return x;
+}
+__device__ __forceinline__ UTri load_ltri(const DevTriGeom* geom, uint32_t slot) {
+    const u32x4* q = (const u32x4*)((const char*)geom + (size_t)slot * sizeof(DevTriGeom));
+    const u32x4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4];
+    UTri t;
+    t.v1x = mkd(a[0], a[1]); t.v1y = mkd(a[2], a[3]); t.v1z = mkd(b[0], b[1]);
+    t.e1x = mkd(b[2], b[3]); t.e1y = mkd(c[0], c[1]); t.e1z = mkd(c[2], c[3]);
+    t.e2x = mkd(d[0], d[1]); t.e2y = mkd(d[2], d[3]); t.e2z = mkd(e[0], e[1]);
+    t.pos = e[2];
+    return t;
+}
+
+// Ray::intersect_with_octant_with_max_t(octree, 0, max_t), ray.rs:104-168: same contract as traverse() above.
+template <bool kGroups>
+__device__ __forceinline__ void traverse_ray(PROF_DECL const DevScene& S, const Stack& stk, bool active, bool any_ok, bool filter_ok, V3 o, V3 d, double max_t,
+                                             double& out_t, uint32_t& out_slot) {
+    bool done = !active;
+    uint32_t cur = 0, sp = 0;
+    double ret_t = kInf; uint32_t ret_slot = kNone;
+    const DevNode* nodes = S.nodes; const DevTriGeom* geom = S.geom; const DevSuper* supers = S.supers;
+    const DevClusterBox* cboxes = S.cboxes; const DevClusterBox* child_boxes = S.child_boxes; const DevClusterBox* tboxes = S.tboxes;
+    const Ray32 r32 = make_ray32(o, d, S.cull_limit, S.cull_enabled != 0 && filter_ok);
+    const RayRcp RR = make_ray_rcp(o, d, S.bounds_plain != 0);
+    PROF_ADD(6, 1); PROF_ADD(7, __popcll(__ballot(active)));
+    PROF_T(5);
+    while (__builtin_amdgcn_ballot_w64(!done) != 0ull) {
+        if (done) continue;
+        const UHead N = load_lhead(nodes, cur);
+        const uint32_t fc = N.first_child, sb = N.sup_begin, sc = N.sup_count, fl = N.flags;
+        PROF_ADD(0, 1); PROF_ADD(1, __popcll(__ballot(1)));
+        PROF_T(0);
+        uint32_t order = 0, nchild = 0, leaf_hit = 0;
+        double own_t = (sp == 0) ? max_t : kInf;                         // ray.rs:117 (children are entered with +inf, ray.rs:96-102,153)
+        uint32_t own_slot = kNone, own_pos = 0;
+        if (fl & 0x100u) {
+            if (fc != 0) {
+                // (1) conservative fp32 filter against the tight bounds of each non-empty child's subtree, as in traverse()
+                uint32_t reach = 0;
+                const DevClusterBox* cb = child_boxes + (fc - 1u);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const UBox B = load_lbox6(cb + k); reach |= slab32(B, r32) ? (1u << k) : 0u; }
+                reach &= fl & 0xFFu;                                     // children with triangle_count 0 return None at once (ray.rs:112)
+                if (reach) {
+                    // (2) exact slab tests from the nine plane quotients (see traverse())
+                    const UPlanes NP = load_lplanes(nodes, cur, N.mid2);
+                    double qlx, qmx, qhx, qly, qmy, qhy, qlz, qmz, qhz;
+                    if (RR.plain) {
+                        qlx = quot(NP.lo[0] - o.x, d.x, RR.rx); qmx = quot(NP.mid[0] - o.x, d.x, RR.rx); qhx = quot(NP.hi[0] - o.x, d.x, RR.rx);
+                        qly = quot(NP.lo[1] - o.y, d.y, RR.ry); qmy = quot(NP.mid[1] - o.y, d.y, RR.ry); qhy = quot(NP.hi[1] - o.y, d.y, RR.ry);
+                        qlz = quot(NP.lo[2] - o.z, d.z, RR.rz); qmz = quot(NP.mid[2] - o.z, d.z, RR.rz); qhz = quot(NP.hi[2] - o.z, d.z, RR.rz);
+                    } else {
+                        qlx = (NP.lo[0] - o.x) / d.x; qmx = (NP.mid[0] - o.x) / d.x; qhx = (NP.hi[0] - o.x) / d.x;
+                        qly = (NP.lo[1] - o.y) / d.y; qmy = (NP.mid[1] - o.y) / d.y; qhy = (NP.hi[1] - o.y) / d.y;
+                        qlz = (NP.lo[2] - o.z) / d.z; qmz = (NP.mid[2] - o.z) / d.z; qhz = (NP.hi[2] - o.z) / d.z;
+                    }
+                    double tk[8]; uint32_t vmask = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        constexpr int hx[8] = {0, 0, 1, 1, 0, 0, 1, 1}, hy[8] = {0, 0, 0, 0, 1, 1, 1, 1}, hz[8] = {0, 1, 1, 0, 0, 1, 1, 0};
+                        double t = kInf;
+                        const bool v = slab_from_quotients(hx[k] ? qmx : qlx, hx[k] ? qhx : qmx, hy[k] ? qmy : qly, hy[k] ? qhy : qmy, hz[k] ? qmz : qlz, hz[k] ? qhz : qmz, t) && ((reach >> k) & 1u);
+                        tk[k] = (!v || t != t) ? kInf : t;                                               // NaN sorts last (reference panics, ray.rs:147)
+                        vmask |= v ? (1u << k) : 0u;
+                    }
+                    // leaf children: their one triangle is tested here, at the parent (see traverse())
+                    uint32_t lm = (fl >> 9) & vmask;
+                    while (lm) {
+                        const uint32_t k = (uint32_t)__builtin_ctz(lm);
+                        lm &= lm - 1u;
+                        const UTri tri = load_ltri(geom, N.leaf_base + (uint32_t)__builtin_popcount((fl >> 9) & ((1u << k) - 1u)));
+                        double tl;
+                        PROF_ADD(2, 1); PROF_ADD(3, __popcll(__ballot(1)));
+                        if (mt_uniform(tri, o, d, tl)) leaf_hit |= 1u << k; else vmask &= ~(1u << k);
+                    }
+                    // stable ascending sort by t (ray.rs:146-147) as a rank computation: every pair (j < k) once -- j goes first iff t_j <= t_k
+                    // (no NaN left in tk) -- and nothing to do for the lanes of a wave none of which has two candidates
+                    if (__builtin_amdgcn_ballot_w64((vmask & (vmask - 1u)) != 0u) == 0ull) {
+                        if (vmask) { order = (uint32_t)__builtin_ctz(vmask); nchild = 1u; }
+                    } else {
+                        uint32_t rank[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                        for (int k = 1; k < 8; ++k) {
+#pragma unroll
+                            for (int j = 0; j < k; ++j) {
+                                const bool both = ((vmask >> j) & (vmask >> k) & 1u) != 0u;
+                                const bool j_first = tk[j] <= tk[k];
+                                rank[k] += (both && j_first) ? 1u : 0u;
+                                rank[j] += (both && !j_first) ? 1u : 0u;
+                            }
+                        }
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) if ((vmask >> k) & 1u) { order |= (uint32_t)k << (3u * rank[k]); nchild++; }
+                    }
+                }
+            }
+            PROF_T(1);
+            // ---- own list (ray.rs:119-129): super-cluster box -> cluster boxes -> triangle boxes -> triangles, all per lane
+            // (the record of the next super-cluster is requested before this one is tested: one memory round trip per iteration instead of two in a row)
+            UBox SP; SP.a = N.s0_begin; SP.b = N.s0_count; SP.cx = SP.cy = SP.cz = SP.hx = SP.hy = SP.hz = 0.0f;
+            if (sc > 1u) SP = load_lbox8(supers + sb);
+            for (uint32_t si = 0; si < sc; ++si) {
+                UBox SN = SP;
+                if (si + 1u < sc) SN = load_lbox8(supers + sb + si + 1u);
+                const uint32_t tb = SP.a, tn = SP.b;
+                const bool hs = (sc == 1u) || slab32(SP, r32);
+                PROF_ADD(10, 1);
+                if constexpr (kGroups) {
+                    if (sc > 1u && tn == 0u) {                                                           // group record (clusters.cpp): skip its super-clusters if out of reach
+                        if (!hs) { si += tb; if (si + 1u < sc) SN = load_lbox8(supers + sb + si + 1u); }
+                        SP = SN;
+                        continue;
+                    }
+                }
+                SP = SN;
+                if (!hs) continue;
+                const uint32_t nc = (tn + 7u) >> 3;
+                UBox CB = load_lbox6(cboxes + (tb >> 3));
+                for (uint32_t c = 0; c < nc; ++c) {
+                    UBox CN = CB;
+                    if (c + 1u < nc) CN = load_lbox6(cboxes + (tb >> 3) + c + 1u);
+                    PROF_ADD(11, 1);
+                    const bool hc = slab32(CB, r32);
+                    CB = CN;
+                    if (!hc) continue;
+                    const uint32_t cb0 = tb + 8u * c, cn = (tn - 8u * c < 8u) ? tn - 8u * c : 8u;
+                    UBox TB = load_lbox6(tboxes + cb0);
+                    for (uint32_t i = 0; i < cn; ++i) {
+                        UBox TN = TB;
+                        if (i + 1u < cn) TN = load_lbox6(tboxes + cb0 + i + 1u);
+                        PROF_ADD(4, 1);
+                        const bool ht = slab32(TB, r32);
+                        TB = TN;
+                        if (!ht) continue;
+                        const UTri tri = load_ltri(geom, cb0 + i);
+                        double t;
+                        PROF_ADD(2, 1); PROF_ADD(3, __popcll(__ballot(1)));
+                        if (mt_uniform(tri, o, d, t) && (t < own_t || (t == own_t && tri.pos < own_pos))) { own_t = t; own_slot = cb0 + i; own_pos = tri.pos; }
+                    }
+                }
+            }
+        }
+        PROF_T(2);
+        // ---- return / push / unwind: ray.rs:152-167, as in traverse()
+        bool returning;
+        if (!(fl & 0x100u)) { returning = true; ret_slot = kNone; ret_t = kInf; }                    // triangle_count == 0 -> None, ray.rs:112-114
+        else if (nchild == 0 || (any_ok && sp == 0 && own_slot != kNone)) { returning = true; ret_slot = own_slot; ret_t = own_t; }
+        else {
+            stk.own_slot(sp) = own_slot; stk.meta(sp) = order | (nchild << 24); stk.fc(sp) = fc | (leaf_hit << 24);
+            sp++;
+            returning = false;
+        }
+        for (;;) {
+            if (!returning) {
+                const uint32_t m = stk.meta(sp - 1);
+                const uint32_t cursor = m >> 28, n = (m >> 24) & 15u;
+                if (cursor < n) {
+                    stk.meta(sp - 1) = m + (1u << 28);
+                    const uint32_t fcw = stk.fc(sp - 1), k = (m >> (3u * cursor)) & 7u;
+                    const uint32_t fcm = S.fc_mask;
+                    if (!(((fcw & ~fcm) >> (24u + k)) & 1u)) { cur = (fcw & fcm) + k; break; }
+                    ret_slot = nodes[(fcw & fcm) + k].leaf_base;
+                    ret_t = t_of_slot(geom + ret_slot, o, d);
+                } else {
+                    ret_slot = stk.own_slot(sp - 1);
+                    ret_t = (ret_slot != kNone) ? t_of_slot(geom + ret_slot, o, d) : kInf;
+                    sp--;
+                }
+                returning = true;
+            }
+            if (sp == 0) { done = true; break; }
+            if (ret_slot != kNone) {
+                const uint32_t ps = stk.own_slot(sp - 1);
+                const double pt = (ps != kNone) ? t_of_slot(geom + ps, o, d) : ((sp == 1) ? max_t : kInf);
+                if (!(ret_t < pt)) { ret_t = pt; ret_slot = ps; }
+                sp--;
+            } else {
+                returning = false;
+            }
+        }
+        PROF_T(3);
+    }
+    out_t = ret_t; out_slot = ret_slot;
+}
+
 // ------------------------------------------------------------------------------------------------ shading helpers
 __device__ __forceinline__ uint64_t f64_as_usize(double x) {   // Rust `as usize`: saturating, NaN -> 0 (raytracer.rs:52-53)
     if (!(x > 0.0)) return 0;
@@ -937,7 +1164,9 @@ __device__ __forceinline__ V3 specular_term(double sw, double intensity, V3 norm
 }
 
 // RayTracer::get_ray_colour (raytracer.rs:29-112) for 64 lanes; wave-uniform call.  Returns 0x00RRGGBB.
-template <bool kBundle, bool kGroups>
+// kWalk: 0 = node-coherent walk, lane filter; 1 = node-coherent walk, bundle filter; 2 = ray walk (one node per lane)
+constexpr int kWalkLane = 0, kWalkBundle = 1, kWalkRay = 2;
+template <int kWalk, bool kGroups>
 __device__ __forceinline__ uint32_t trace_colour(PROF_DECL const DevScene& S, const Stack& stk, bool active, V3 origin, V3 direction) {
     bool live = active;
     bool in_shadow = false;                 // false: the ray in flight is a segment (primary/reflection) ray; true: a shadow ray
@@ -953,7 +1182,18 @@ __device__ __forceinline__ uint32_t trace_colour(PROF_DECL const DevScene& S, co
     while (__any(live)) {
         double t; uint32_t slot;
         PROF_T(4);                                                       // [4] shading / state machine between traversals
-        traverse<kBundle, kGroups>(PROF_ARG S, stk, live, in_shadow, !(first_unfiltered && depth == 0u && !in_shadow), ro, rd, rmax, t, slot);
+#ifdef RRT_MIXED_POLICY   /* developer experiment: kWalkRay instantiation runs the lane walk for some traversals */
+        if constexpr (kWalk == kWalkRay) {
+            const unsigned long long lv = __builtin_amdgcn_ballot_w64(live), sh = __builtin_amdgcn_ballot_w64(live && in_shadow);
+            const bool use_ray = (RRT_MIXED_POLICY == 1) ? (2 * __popcll(sh) >= __popcll(lv)) : (2 * __popcll(sh) < __popcll(lv));
+            if (use_ray) traverse_ray<kGroups>(PROF_ARG S, stk, live, in_shadow, !(first_unfiltered && depth == 0u && !in_shadow), ro, rd, rmax, t, slot);
+            else traverse<false, kGroups>(PROF_ARG S, stk, live, in_shadow, !(first_unfiltered && depth == 0u && !in_shadow), ro, rd, rmax, t, slot);
+        } else
+#else
+        if constexpr (kWalk == kWalkRay) traverse_ray<kGroups>(PROF_ARG S, stk, live, in_shadow, !(first_unfiltered && depth == 0u && !in_shadow), ro, rd, rmax, t, slot);
+        else
+#endif
+        traverse<kWalk == kWalkBundle, kGroups>(PROF_ARG S, stk, live, in_shadow, !(first_unfiltered && depth == 0u && !in_shadow), ro, rd, rmax, t, slot);
         if (live) {
             const bool found = slot != kNone;
             if (!in_shadow) {
@@ -1085,8 +1325,11 @@ __device__ __forceinline__ uint32_t trace_colour(PROF_DECL const DevScene& S, co
 #ifndef RRT_WAVES_BUNDLE
 #define RRT_WAVES_BUNDLE 4
 #endif
-template <bool kBundle, bool kGroups>
-__global__ __launch_bounds__(64, kBundle ? RRT_WAVES_BUNDLE : RRT_WAVES_LANE) void render_kernel(const DevScene S, const FrameParams F, uint32_t* __restrict__ out) {
+#ifndef RRT_WAVES_RAY
+#define RRT_WAVES_RAY 4
+#endif
+template <int kWalk, bool kGroups>
+__global__ __launch_bounds__(64, kWalk == kWalkBundle ? RRT_WAVES_BUNDLE : kWalk == kWalkLane ? RRT_WAVES_LANE : RRT_WAVES_RAY) void render_kernel(const DevScene S, const FrameParams F, uint32_t* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const uint32_t lane = threadIdx.x;
     const Stack stk{lds + kParkBytes, lane};
@@ -1111,7 +1354,7 @@ __global__ __launch_bounds__(64, kBundle ? RRT_WAVES_BUNDLE : RRT_WAVES_LANE) vo
 #ifdef RRT_PROFILE
     Prof prof{}; prof.last = __builtin_amdgcn_s_memtime();
 #endif
-    const uint32_t c = trace_colour<kBundle, kGroups>(PROF_ARG S, stk, traced, ld3(S.origin), dir);
+    const uint32_t c = trace_colour<kWalk, kGroups>(PROF_ARG S, stk, traced, ld3(S.origin), dir);
 #ifdef RRT_PROFILE
     PROF_T(4);
     for (int i = 0; i < 16; i++) if (prof.c[i]) atomicAdd(S.prof + i, prof.c[i]);
@@ -1141,7 +1384,7 @@ __global__ __launch_bounds__(256) void detile_kernel(uint32_t width, uint32_t he
     fb[i] = gathered[((size_t)r * tiles_per_rank + lt) * 64 + ((py & 7u) * 8 + (px & 7u))];
 }
 
-template <bool kBundle>
+template <int kWalk>
 __global__ __launch_bounds__(64) void ray_colour_kernel(const DevScene S, uint32_t n, const double* __restrict__ origins, const double* __restrict__ dirs,
                                                         uint32_t* __restrict__ colours) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -1152,11 +1395,11 @@ __global__ __launch_bounds__(64) void ray_colour_kernel(const DevScene S, uint32
 #ifdef RRT_PROFILE
     Prof prof{}; prof.last = 0;
 #endif
-    const uint32_t c = trace_colour<kBundle, true>(PROF_ARG S, stk, ok, o, d);
+    const uint32_t c = trace_colour<kWalk, true>(PROF_ARG S, stk, ok, o, d);
     if (ok) colours[i] = c;
 }
 
-template <bool kBundle>
+template <int kWalk>
 __global__ __launch_bounds__(64) void intersect_kernel(const DevScene S, uint32_t n, const double* __restrict__ origins, const double* __restrict__ dirs,
                                                        const double* __restrict__ max_t, uint8_t* __restrict__ hit, double* __restrict__ t_out,
                                                        double* __restrict__ u_out, double* __restrict__ v_out, uint32_t* __restrict__ tri_out) {
@@ -1170,7 +1413,8 @@ __global__ __launch_bounds__(64) void intersect_kernel(const DevScene S, uint32_
 #ifdef RRT_PROFILE
     Prof prof{}; prof.last = 0;
 #endif
-    traverse<kBundle, true>(PROF_ARG S, stk, ok, false, !origin_ray_in_suspect_plane(S, o, d), o, d, mt, t, slot);
+    if constexpr (kWalk == kWalkRay) traverse_ray<true>(PROF_ARG S, stk, ok, false, !origin_ray_in_suspect_plane(S, o, d), o, d, mt, t, slot);
+    else traverse<kWalk == kWalkBundle, true>(PROF_ARG S, stk, ok, false, !origin_ray_in_suspect_plane(S, o, d), o, d, mt, t, slot);
     if (!ok) return;
     if (slot == kNone) { hit[i] = 0; t_out[i] = 0; u_out[i] = 0; v_out[i] = 0; tri_out[i] = kNone; return; }
     double t2, u = 0, v = 0;
@@ -1184,8 +1428,9 @@ __global__ __launch_bounds__(64) void intersect_kernel(const DevScene S, uint32_
 // while the host is still parsing the scene (api.cpp, warm_device_async).
 void preload_kernels() {
     hipFuncAttributes a;
-    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&render_kernel<true, false>));
-    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&render_kernel<false, false>));
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&render_kernel<kWalkBundle, false>));
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&render_kernel<kWalkLane, false>));
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&render_kernel<kWalkRay, false>));
     (void)hipGetLastError();
 }
 
@@ -1199,7 +1444,7 @@ uint32_t stack_bytes_per_wave(uint32_t levels) { return kParkBytes + levels * kL
 #include <cstdlib>
 #include <vector>
 namespace rrt {
-static int dev_hsaco_launch(const DevScene& s, const FrameParams& f, uint32_t* d_out, hipStream_t stream, bool bundle, dim3 grid, uint32_t lds) {
+static int dev_hsaco_launch(const DevScene& s, const FrameParams& f, uint32_t* d_out, hipStream_t stream, int walk, dim3 grid, uint32_t lds) {
     static hipModule_t mod = nullptr; static uint32_t* d_cnt = nullptr;
     constexpr size_t kCnt = 16 * 64;
     if (!mod) {
@@ -1207,7 +1452,7 @@ static int dev_hsaco_launch(const DevScene& s, const FrameParams& f, uint32_t* d
         if (hipMalloc((void**)&d_cnt, kCnt * 4) != hipSuccess) abort();
     }
     char name[160];
-    snprintf(name, sizeof name, "_ZN3rrt12_GLOBAL__N_113render_kernelILb%dELb%dEEEvNS_8DevSceneENS_11FrameParamsEPj", bundle ? 1 : 0, s.has_groups ? 1 : 0);
+    snprintf(name, sizeof name, "_ZN3rrt12_GLOBAL__N_113render_kernelILi%dELb%dEEEvNS_8DevSceneENS_11FrameParamsEPj", walk, s.has_groups ? 1 : 0);
     hipFunction_t fn;
     if (hipModuleGetFunction(&fn, mod, name) != hipSuccess) { fprintf(stderr, "RRT_DEV_HSACO: no kernel %s\n", name); abort(); }
     struct Args { DevScene s; FrameParams f; uint32_t* out; } a{s, f, d_out};
@@ -1227,21 +1472,28 @@ static int dev_hsaco_launch(const DevScene& s, const FrameParams& f, uint32_t* d
 }
 #endif
 
-int launch_render(const DevScene& s, const FrameParams& f, uint32_t* d_out, void* stream, bool bundle) {
+int launch_render(const DevScene& s, const FrameParams& f, uint32_t* d_out, void* stream, int walk) {
     const uint32_t n_tiles = f.tile_end > f.tile_begin ? f.tile_end - f.tile_begin : 0u;
     const uint32_t local_tiles = (n_tiles + f.world - 1) / f.world;
     if (local_tiles == 0) return 0;
 #ifdef RRT_DEV_HSACO
-    if (getenv("RRT_DEV_HSACO")) return dev_hsaco_launch(s, f, d_out, (hipStream_t)stream, bundle, dim3(local_tiles * 4), stack_bytes_per_wave(s.stack_levels));
+    if (getenv("RRT_DEV_HSACO")) return dev_hsaco_launch(s, f, d_out, (hipStream_t)stream, walk, dim3(local_tiles * 4), stack_bytes_per_wave(s.stack_levels));
 #endif
-    // (four instantiations: the group-record handling of long own lists, clusters.cpp, is compiled in only for scenes that have such lists --
+    // (two instantiations per walk: the group-record handling of long own lists, clusters.cpp, is compiled in only for scenes that have such lists --
     // its few instructions in the super-cluster loop cost the other scenes 5 % through register allocation alone, measured)
     const dim3 grid(local_tiles * 4), block(64);
     const uint32_t lds = stack_bytes_per_wave(s.stack_levels);
-    if (bundle && s.has_groups) hipLaunchKernelGGL((render_kernel<true, true>), grid, block, lds, (hipStream_t)stream, s, f, d_out);
-    else if (bundle) hipLaunchKernelGGL((render_kernel<true, false>), grid, block, lds, (hipStream_t)stream, s, f, d_out);
-    else if (s.has_groups) hipLaunchKernelGGL((render_kernel<false, true>), grid, block, lds, (hipStream_t)stream, s, f, d_out);
-    else hipLaunchKernelGGL((render_kernel<false, false>), grid, block, lds, (hipStream_t)stream, s, f, d_out);
+    const hipStream_t q = (hipStream_t)stream;
+    if (walk == kWalkBundle) {
+        if (s.has_groups) hipLaunchKernelGGL((render_kernel<kWalkBundle, true>), grid, block, lds, q, s, f, d_out);
+        else hipLaunchKernelGGL((render_kernel<kWalkBundle, false>), grid, block, lds, q, s, f, d_out);
+    } else if (walk == kWalkRay) {
+        if (s.has_groups) hipLaunchKernelGGL((render_kernel<kWalkRay, true>), grid, block, lds, q, s, f, d_out);
+        else hipLaunchKernelGGL((render_kernel<kWalkRay, false>), grid, block, lds, q, s, f, d_out);
+    } else {
+        if (s.has_groups) hipLaunchKernelGGL((render_kernel<kWalkLane, true>), grid, block, lds, q, s, f, d_out);
+        else hipLaunchKernelGGL((render_kernel<kWalkLane, false>), grid, block, lds, q, s, f, d_out);
+    }
     return (int)hipGetLastError();
 }
 
@@ -1254,20 +1506,24 @@ int launch_detile(uint32_t width, uint32_t height, uint32_t world, const uint32_
     return (int)hipGetLastError();
 }
 
-int launch_ray_colours(const DevScene& s, uint32_t n, const double* d_origins, const double* d_dirs, uint32_t* d_colours, void* stream, bool bundle) {
+int launch_ray_colours(const DevScene& s, uint32_t n, const double* d_origins, const double* d_dirs, uint32_t* d_colours, void* stream, int walk) {
     if (n == 0) return 0;
-    if (bundle) hipLaunchKernelGGL(ray_colour_kernel<true>, dim3((n + 63) / 64), dim3(64), stack_bytes_per_wave(s.stack_levels), (hipStream_t)stream, s, n, d_origins, d_dirs, d_colours);
-    else hipLaunchKernelGGL(ray_colour_kernel<false>, dim3((n + 63) / 64), dim3(64), stack_bytes_per_wave(s.stack_levels), (hipStream_t)stream, s, n, d_origins, d_dirs, d_colours);
+    const dim3 grid((n + 63) / 64), block(64);
+    const uint32_t lds = stack_bytes_per_wave(s.stack_levels);
+    if (walk == kWalkBundle) hipLaunchKernelGGL(ray_colour_kernel<kWalkBundle>, grid, block, lds, (hipStream_t)stream, s, n, d_origins, d_dirs, d_colours);
+    else if (walk == kWalkRay) hipLaunchKernelGGL(ray_colour_kernel<kWalkRay>, grid, block, lds, (hipStream_t)stream, s, n, d_origins, d_dirs, d_colours);
+    else hipLaunchKernelGGL(ray_colour_kernel<kWalkLane>, grid, block, lds, (hipStream_t)stream, s, n, d_origins, d_dirs, d_colours);
     return (int)hipGetLastError();
 }
 
 int launch_intersect(const DevScene& s, uint32_t n, const double* d_origins, const double* d_dirs, const double* d_max_t,
-                     uint8_t* d_hit, double* d_t, double* d_u, double* d_v, uint32_t* d_tri, void* stream, bool bundle) {
+                     uint8_t* d_hit, double* d_t, double* d_u, double* d_v, uint32_t* d_tri, void* stream, int walk) {
     if (n == 0) return 0;
-    if (bundle) hipLaunchKernelGGL(intersect_kernel<true>, dim3((n + 63) / 64), dim3(64), stack_bytes_per_wave(s.stack_levels), (hipStream_t)stream, s, n, d_origins, d_dirs,
-                       d_max_t, d_hit, d_t, d_u, d_v, d_tri);
-    else hipLaunchKernelGGL(intersect_kernel<false>, dim3((n + 63) / 64), dim3(64), stack_bytes_per_wave(s.stack_levels), (hipStream_t)stream, s, n, d_origins, d_dirs,
-                       d_max_t, d_hit, d_t, d_u, d_v, d_tri);
+    const dim3 grid((n + 63) / 64), block(64);
+    const uint32_t lds = stack_bytes_per_wave(s.stack_levels);
+    if (walk == kWalkBundle) hipLaunchKernelGGL(intersect_kernel<kWalkBundle>, grid, block, lds, (hipStream_t)stream, s, n, d_origins, d_dirs, d_max_t, d_hit, d_t, d_u, d_v, d_tri);
+    else if (walk == kWalkRay) hipLaunchKernelGGL(intersect_kernel<kWalkRay>, grid, block, lds, (hipStream_t)stream, s, n, d_origins, d_dirs, d_max_t, d_hit, d_t, d_u, d_v, d_tri);
+    else hipLaunchKernelGGL(intersect_kernel<kWalkLane>, grid, block, lds, (hipStream_t)stream, s, n, d_origins, d_dirs, d_max_t, d_hit, d_t, d_u, d_v, d_tri);
     return (int)hipGetLastError();
 }
 

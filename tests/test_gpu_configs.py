@@ -132,7 +132,7 @@ def test_config2_soup100k_1080p(rrt, soup100k):
     check_rays_bit_exact(rt, osc, O, D, M, 5000, 0.3)
     exact = rrt.RayTracer(sd, lights, no_cull=True)
     assert np.array_equal(exact.render(w, h), a), "default (indexed) frame differs from the reference-order (no_cull) frame"
-    for mode in ("lane", "bundle"):
+    for mode in ("lane", "bundle", "ray"):
         assert np.array_equal(rrt.RayTracer(sd, lights, box_filter=mode).render(w, h), a), mode
 
 
@@ -263,7 +263,7 @@ def test_filter_exactness_guard_near_coplanar_rays_at_scale(rrt):
     D[N // 2:] = np.stack([rng.uniform(-0.5, 0.5, N - N // 2), rng.uniform(-0.35, 0.35, N - N // 2), np.ones(N - N // 2)], -1)   # ordinary rays beside them
     exact = rrt.RayTracer(sd, lights, no_cull=True).intersect_rays(O, D)
     assert 0.2 < exact[0].mean() <= 1.0
-    for mode in ("lane", "bundle", None):
+    for mode in ("lane", "bundle", "ray", None):
         rt = rrt.RayTracer(sd, lights, box_filter=mode)
         assert rt.last_stats()["origin_plane_triangles"] == 60
         got = rt.intersect_rays(O, D)
@@ -278,7 +278,7 @@ def test_filter_exactness_guard_near_coplanar_rays_at_scale(rrt):
     N = 200_000
     O, D = _coplanar_rays(rng, tris, planes, 4000, o0, N)
     exact = rrt.RayTracer(sd, lights, no_cull=True).intersect_rays(O, D)
-    for mode in ("lane", "bundle"):
+    for mode in ("lane", "bundle", "ray"):
         rt = rrt.RayTracer(sd, lights, box_filter=mode)
         assert rt.last_stats()["origin_plane_triangles"] == 4000
         for name, x, y in zip(("hit", "t", "u", "v", "tri"), rt.intersect_rays(O, D), exact):

@@ -70,7 +70,7 @@ def test_random_rays_with_max_t_bit_exact(teapot_rt, teapot_oracle):
     assert 0.2 < hit.mean() < 0.95
 
 
-@pytest.mark.parametrize("mode", ["lane", "bundle"])
+@pytest.mark.parametrize("mode", ["lane", "bundle", "ray"])
 def test_extreme_ray_magnitudes_bit_exact(rrt, teapot, teapot_oracle, mode):
     """Rays whose components leave the range in which the walk may share one reciprocal per axis across its slab quotients (render.hip, RayRcp:
     |d| in [2^-500, 2^500], origin components 0 or in [2^-200, 2^200]) must take the ordinary divide and still agree bit for bit: directions scaled by
@@ -138,18 +138,19 @@ def test_cluster_index_is_result_preserving(rrt, name, w, h):
     sd = rrt.parse_obj_file(os.path.join(ASSETS, name))
     fast = rrt.RayTracer(sd, rrt.default_lights()); exact = rrt.RayTracer(sd, rrt.default_lights(), no_cull=True)
     lane = rrt.RayTracer(sd, rrt.default_lights(), box_filter="lane"); bundle = rrt.RayTracer(sd, rrt.default_lights(), box_filter="bundle")
+    ray = rrt.RayTracer(sd, rrt.default_lights(), box_filter="ray")
     ref = exact.render(w, h)
-    assert np.array_equal(fast.render(w, h), ref) and np.array_equal(lane.render(w, h), ref) and np.array_equal(bundle.render(w, h), ref)
-    assert lane.last_stats()["filter_variant"] == 0 and bundle.last_stats()["filter_variant"] == 1
+    assert np.array_equal(fast.render(w, h), ref) and np.array_equal(lane.render(w, h), ref) and np.array_equal(bundle.render(w, h), ref) and np.array_equal(ray.render(w, h), ref)
+    assert lane.last_stats()["filter_variant"] == 0 and bundle.last_stats()["filter_variant"] == 1 and ray.last_stats()["filter_variant"] == 2
     rng = np.random.default_rng(11)
     n = 20000
     o = rng.uniform([-5, -0.5, -8], [5, 6, 5], (n, 3)); d = rng.normal(size=(n, 3)); d[:500, rng.integers(0, 3)] = 0.0
     mt = rng.uniform(0.5, 40.0, n); mt[::3] = np.inf
     b = exact.intersect_rays(o, d, mt)
-    for other in (fast, lane, bundle):                      # incoherent random rays: the bundle's interval test degenerates gracefully
+    for other in (fast, lane, bundle, ray):                 # incoherent random rays: the bundle's interval test degenerates gracefully
         for x, y in zip(other.intersect_rays(o, d, mt), b):
             assert np.array_equal(x, y)
-    assert np.array_equal(bundle.get_ray_colours(o[:4096], d[:4096]), exact.get_ray_colours(o[:4096], d[:4096]))
+    for other in (bundle, ray): assert np.array_equal(other.get_ray_colours(o[:4096], d[:4096]), exact.get_ray_colours(o[:4096], d[:4096]))
     big = rrt.RayTracer(sd, rrt.default_lights(), rrt.Vector3d(1e4, 2.0, -10.0))       # origin beyond the fp32 filter's scale limit: filter must switch itself off
     big_exact = rrt.RayTracer(sd, rrt.default_lights(), rrt.Vector3d(1e4, 2.0, -10.0), no_cull=True)
     assert np.array_equal(big.render(64, 48), big_exact.render(64, 48))
@@ -318,7 +319,7 @@ def test_adversarial_random_scenes(rrt, ob, kind):
     ref, _ = osc.render(w, h)
     exact = rrt.RayTracer(sd, lights, no_cull=True).render(w, h)
     assert_frame_close(exact, ref, f"{kind} no_cull vs oracle")
-    for mode in (None, "lane", "bundle"):
+    for mode in (None, "lane", "bundle", "ray"):
         got = rrt.RayTracer(sd, lights, box_filter=mode).render(w, h)
         assert np.array_equal(got, exact), f"{kind}: filter {mode} differs from no_cull on {(got != exact).sum()} pixels"
 
@@ -366,7 +367,7 @@ def test_progressive_draw_matches_reference_pacing(rrt, teapot_rt, w, h, chunk):
     assert np.array_equal(sc.canvas.buffer, full) and sc.canvas.updates == len(range(-half, half, 50))   # the reference's chunk size, engine.rs:195
 
 
-@pytest.mark.parametrize("mode", ["lane", "bundle", "no_cull"])
+@pytest.mark.parametrize("mode", ["lane", "bundle", "ray", "no_cull"])
 def test_deep_octree_rays_bit_exact(rrt, ob, mode):
     """Clusters of many tiny triangles a hair apart: a leaf splits whenever a second triangle arrives (octree.rs:79-92), so the tree goes ~20 levels deep
     before it separates them -- long LDS stacks, long unwinds, leaf children at every level.  Rays aimed at the triangles (and just past them) must
@@ -428,7 +429,7 @@ def test_long_own_list_with_group_records(rrt, ob):
     assert ((ref != 0xFFFFFF) & (ref != 0)).mean() > 0.02
     exact = rrt.RayTracer(sd, lights, no_cull=True).render(160, 120)
     assert_frame_close(exact, ref, "long list, reference order")
-    for mode in ("lane", "bundle", None):
+    for mode in ("lane", "bundle", "ray", None):
         assert np.array_equal(rrt.RayTracer(sd, lights, box_filter=mode).render(160, 120), exact), mode
     cam = np.array([0.0, 2.0, -10.0])
     tgt = tris.mean(1)[::7] + rng.normal(size=(len(tris[::7]), 3)) * 0.02

@@ -16,7 +16,7 @@ for name, path, w, h in cases:
     pos, uv, nrm, mat = sd.triangles()
     osc = ob.OracleScene(pos, uv, nrm, mat, sd.materials(), sd.textures(), lt, (0.0, 2.0, -10.0))
     t0 = time.time(); ref, cnt = osc.render(w, h, n_threads=os.cpu_count()); to = time.time() - t0
-    for mode in (None, "lane", "bundle"):
+    for mode in (None, "lane", "bundle", "ray"):
         g = rrt.RayTracer(sd, lights, box_filter=mode).render(w, h)
         ch = lambda a: np.stack([(a >> 16) & 255, (a >> 8) & 255, a & 255], -1).astype(np.int64)
         d = np.abs(ch(g) - ch(ref))
