@@ -506,6 +506,7 @@ int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n
                     if (!(v == 0.0 || (std::fabs(v) > 0x1p-200 && std::fabs(v) < 0x1p200))) S.bounds_plain = 0u;
         }
         S.cull_limit = (float)(CS.scene_magnitude * 4.0);
+        S.cull_half_over_limit = S.cull_limit > 0.0f ? 0.5f / S.cull_limit : 0.0f;
         lap("geometry + index enqueued");
         std::vector<DevSuspect> sus;                                      // (lives until the hipDeviceSynchronize below: uploads are asynchronous)
         {   // exactness guard of the index for rays from `origin` (clusters.cpp, find_origin_suspects)

@@ -80,6 +80,7 @@ struct DevScene {                // passed to kernels by value (kernarg segment 
     double origin[3];
     double surface_offset;
     float cull_limit;            // rays with |origin| or |direction| components beyond this (or non-finite) skip the box culling
+    float cull_half_over_limit;  // 0.5 / cull_limit (the fp32 filter's parameter scale, render.hip make_ray32)
     uint32_t cull_enabled;
     uint32_t has_groups;         // some own list carries group records (clusters.cpp): launches use the kernel instantiation that handles them
     uint32_t n_suspects;         // triangles whose plane passes through `origin` (see DevSuspect); more than RRT_MAX_SUSPECTS: every ray from `origin` runs unfiltered

@@ -269,29 +269,75 @@ __device__ __forceinline__ bool slab_from_quotients(double t1, double t2, double
 // A direction component smaller than 1e-20 is treated as parallel (inv = 1e30): over any t that matters the ray does not move along
 // that axis by more than the box padding.  Rays with non-finite or out-of-scale components (and every ray in RRT_FLAG_NO_CULL mode) get
 // inv = n = 0: all six slab values are then 0 and every box tests as hit, i.e. the filter is off for that lane.
-struct Ray32 { float ix, iy, iz, nx, ny, nz, ax, ay, az; };   // ax = |ix| ...
-__device__ __forceinline__ Ray32 make_ray32(V3 o, V3 d, float limit, bool enabled) {
+// The ray as the packed FMAs below want it: register PAIRS {ix, iy}, {nx, ny}, {|ix|, |iy|}, {iz, |iz|}, {nz, 0}.  The parameter is scaled by
+// sigma = max|d| / (2 limit): every box of the scene is entered before t' = sigma t reaches 1 (|o| < limit = 4 x the scene magnitude, boxes within
+// the scene: at most 1.25 limit along the dominant axis), which lets the near-plane maximum be clamped to [0, 1] by the instruction that forms it.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct Ray32 {
+    f32x2 i01, n01, a01, izaz, nz0; float sigma;
+    __device__ __forceinline__ float ix() const { return i01.x; }
+    __device__ __forceinline__ float iy() const { return i01.y; }
+    __device__ __forceinline__ float iz() const { return izaz.x; }
+};
+__device__ __forceinline__ Ray32 make_ray32(V3 o, V3 d, float limit, float half_over_limit, bool enabled) {
     const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z, dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
-    Ray32 r;
-    const bool cull = enabled && fabsf(ox) < limit && fabsf(oy) < limit && fabsf(oz) < limit && fabsf(dx) < limit && fabsf(dy) < limit && fabsf(dz) < limit;
+    const float dmax = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
+    // (dmax > 1e-10: a component below 1e-20 is treated as parallel, which is only right while the ray cannot cross the scene -- t <= 2 limit / dmax -- by
+    // moving along that axis)
+    const bool cull = enabled && fabsf(ox) < limit && fabsf(oy) < limit && fabsf(oz) < limit && dmax < limit && dmax > 1e-10f;
+    const float sigma = cull ? dmax * half_over_limit : 0.0f;
     // v_rcp_f32 (1 ulp) is plenty for a filter whose boxes are padded by ~1e-5 of the scene: an IEEE divide would cost ten instructions each
-    r.ix = !cull ? 0.0f : fabsf(dx) < 1e-20f ? 1e30f : __builtin_amdgcn_rcpf(dx);
-    r.iy = !cull ? 0.0f : fabsf(dy) < 1e-20f ? 1e30f : __builtin_amdgcn_rcpf(dy);
-    r.iz = !cull ? 0.0f : fabsf(dz) < 1e-20f ? 1e30f : __builtin_amdgcn_rcpf(dz);
-    r.nx = !cull ? 0.0f : -ox * r.ix; r.ny = !cull ? 0.0f : -oy * r.iy; r.nz = !cull ? 0.0f : -oz * r.iz;
-    r.ax = fabsf(r.ix); r.ay = fabsf(r.iy); r.az = fabsf(r.iz);
+    const float ix = !cull ? 0.0f : (fabsf(dx) < 1e-20f ? 1e30f : __builtin_amdgcn_rcpf(dx)) * sigma;
+    const float iy = !cull ? 0.0f : (fabsf(dy) < 1e-20f ? 1e30f : __builtin_amdgcn_rcpf(dy)) * sigma;
+    const float iz = !cull ? 0.0f : (fabsf(dz) < 1e-20f ? 1e30f : __builtin_amdgcn_rcpf(dz)) * sigma;
+    Ray32 r;
+    r.i01.x = ix; r.i01.y = iy; r.izaz.x = iz; r.izaz.y = fabsf(iz);
+    r.n01.x = -ox * ix; r.n01.y = -oy * iy; r.nz0.x = -oz * iz; r.nz0.y = 0.0f;
+    r.a01.x = fabsf(ix); r.a01.y = fabsf(iy);
+    r.sigma = sigma;
     return r;
 }
-// true unless the ray (t >= 0) certainly misses the padded box; the box (centre c, half-extent h) is wave-uniform.  Per axis the slab values
-// of the planes c -/+ h are  (c*inv + n) -/+ h*|inv|: the smaller one is the near plane whatever the sign of the direction.
+// Near-plane maximum (clamped to [0, 1]) and far-plane minimum of one padded box (centre c, half-extent h) along the ray: per axis the slab values of
+// the planes c -/+ h are (c*inv + n) -/+ h*|inv|, the smaller being the near plane whatever the sign of the direction.  The ray cannot reach the box
+// at t >= 0 unless tmin <= tmax.  (tmin is only ever clamped DOWN from above 1, which can only let a box through.)
+// Per-lane box (ray walk):
 __device__ __forceinline__ bool slab32(const UBox& b, const Ray32& r) {
-    const float tx = __builtin_fmaf(b.cx, r.ix, r.nx), ty = __builtin_fmaf(b.cy, r.iy, r.ny), tz = __builtin_fmaf(b.cz, r.iz, r.nz);
-    const float nx = __builtin_fmaf(-b.hx, r.ax, tx), fx = __builtin_fmaf(b.hx, r.ax, tx);
-    const float ny = __builtin_fmaf(-b.hy, r.ay, ty), fy = __builtin_fmaf(b.hy, r.ay, ty);
-    const float nz = __builtin_fmaf(-b.hz, r.az, tz), fz = __builtin_fmaf(b.hz, r.az, tz);
+    const float tx = __builtin_fmaf(b.cx, r.i01.x, r.n01.x), ty = __builtin_fmaf(b.cy, r.i01.y, r.n01.y), tz = __builtin_fmaf(b.cz, r.izaz.x, r.nz0.x);
+    const float nx = __builtin_fmaf(-b.hx, r.a01.x, tx), fx = __builtin_fmaf(b.hx, r.a01.x, tx);
+    const float ny = __builtin_fmaf(-b.hy, r.a01.y, ty), fy = __builtin_fmaf(b.hy, r.a01.y, ty);
+    const float nz = __builtin_fmaf(-b.hz, r.izaz.y, tz), fz = __builtin_fmaf(b.hz, r.izaz.y, tz);
     const float tmin = fmaxf(fmaxf(fmaxf(nx, ny), nz), 0.0f);
     const float tmax = fminf(fminf(fx, fy), fz);
     return tmin <= tmax;
+}
+// Wave-uniform box, its record's first six dwords as three SGPR pairs p0 = {cx, cy}, p1 = {cz, hx}, p2 = {hy, hz}: five packed FMAs give all nine
+// values (v_pk_fma_f32 with an SGPR-pair operand issues in the time of ONE v_fma_f32 with an SGPR operand -- 4.5 cycles per SIMD, measured,
+// tools/probes/issue_probe.hip; min/max cost as much, hence the clamp in place of a separate max with 0): 7 VALU instructions where the plain form
+// above takes 13.
+__device__ __forceinline__ void slab32_pk(unsigned long long p0, unsigned long long p1, unsigned long long p2, const Ray32& r, float& tmin, float& tmax) {
+    f32x2 T, TZ, X, Y, Z;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(T) : "s"(p0), "v"(r.i01), "v"(r.n01));                                        // {cx ix + nx, cy iy + ny}
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(TZ) : "s"(p1), "v"(r.izaz), "v"(r.nz0));                                     // {cz iz + nz, (unused)}
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0] neg_lo:[1,0,0]" : "=v"(X) : "s"(p1), "v"(r.a01), "v"(T));    // tcx -/+ hx |ix|
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(Y) : "s"(p2), "v"(r.a01), "v"(T));    // tcy -/+ hy |iy|
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,1,0] neg_lo:[1,0,0]" : "=v"(Z) : "s"(p2), "v"(r.izaz), "v"(TZ));  // tcz -/+ hz |iz|
+    asm("v_max3_f32 %0, %1, %2, %3 clamp" : "=v"(tmin) : "v"(X.x), "v"(Y.x), "v"(Z.x));
+    tmax = fminf(fminf(X.y, Y.y), Z.y);
+}
+__device__ __forceinline__ unsigned long long sgpr_pair(uint32_t lo, uint32_t hi) { return ((unsigned long long)hi << 32) | lo; }
+__device__ __forceinline__ bool slab32_u(const UBox& b, const Ray32& r) {      // a wave-uniform box held as a UBox (super-cluster records)
+    float tmin, tmax;
+    slab32_pk(sgpr_pair(__builtin_bit_cast(uint32_t, b.cx), __builtin_bit_cast(uint32_t, b.cy)), sgpr_pair(__builtin_bit_cast(uint32_t, b.cz), __builtin_bit_cast(uint32_t, b.hx)),
+              sgpr_pair(__builtin_bit_cast(uint32_t, b.hy), __builtin_bit_cast(uint32_t, b.hz)), r, tmin, tmax);
+    return tmin <= tmax;
+}
+// A burst of boxes: bit i of the lane's accumulator and of the wave's says whether this lane's ray / some lane's ray may hit box i.  The boxes of a
+// burst are tested from the LAST to the first and each result is shifted in from below (acc = 2 acc + hit: one v_addc_co_u32 with the compare's mask
+// as carry-in; the wave's word likewise with s_addc_u32), so box i ends up at bit i whatever the count.
+__device__ __forceinline__ void box_hit_shift(float tmin, float tmax, uint32_t& lane_acc, uint32_t& wave_acc) {
+    unsigned long long m;
+    asm("v_cmp_le_f32_e64 %1, %2, %3\n\tv_addc_co_u32_e64 %0, vcc, %0, %0, %1" : "+v"(lane_acc), "=&s"(m) : "v"(tmin), "v"(tmax) : "vcc");
+    asm("s_cmp_lg_u64 %1, 0\n\ts_addc_u32 %0, %0, %0" : "+s"(wave_acc) : "s"(m) : "scc");
 }
 
 // Exactness guard: must the index filter stay off for this ray?  Only rays that start at the raytracer's origin can be
@@ -385,10 +431,11 @@ __device__ __forceinline__ Bundle make_bundle(bool active, V3 o, V3 d, const Ray
     B.cx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ox), leader));
     B.cy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, oy), leader));
     B.cz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, oz), leader));
-    const float mx = (B.cx - ox) * r.ix + tau, my = (B.cy - oy) * r.iy + tau, mz = (B.cz - oz) * r.iz + tau;
+    const float ts = tau * r.sigma;                                        // the anchor's parameter in the ray's scaled units (make_ray32)
+    const float mx = (B.cx - ox) * r.ix() + ts, my = (B.cy - oy) * r.iy() + ts, mz = (B.cz - oz) * r.iz() + ts;
     const float pinf = __builtin_huge_valf();
     // min over the active lanes of x and of -x (max = -min(-x)); inactive lanes hold +inf
-    float x[12] = {active ? r.ix : pinf, active ? -r.ix : pinf, active ? r.iy : pinf, active ? -r.iy : pinf, active ? r.iz : pinf, active ? -r.iz : pinf,
+    float x[12] = {active ? r.ix() : pinf, active ? -r.ix() : pinf, active ? r.iy() : pinf, active ? -r.iy() : pinf, active ? r.iz() : pinf, active ? -r.iz() : pinf,
                    active ? mx : pinf,   active ? -mx : pinf,   active ? my : pinf,   active ? -my : pinf,   active ? mz : pinf,   active ? -mz : pinf};
     wave_min12_f32(x);
     B.ilx = x[0]; B.ihx = -x[1]; B.ily = x[2]; B.ihy = -x[3]; B.ilz = x[4]; B.ihz = -x[5];
@@ -400,7 +447,7 @@ __device__ __forceinline__ Bundle make_bundle(bool active, V3 o, V3 d, const Ray
     if (B.ilx < 0.0f && B.ihx > 0.0f) { B.ilx = -kBig; B.ihx = kBig; }
     if (B.ily < 0.0f && B.ihy > 0.0f) { B.ily = -kBig; B.ihy = kBig; }
     if (B.ilz < 0.0f && B.ihz > 0.0f) { B.ilz = -kBig; B.ihz = kBig; }
-    if (act == 0ull || __builtin_amdgcn_ballot_w64(active && r.ix == 0.0f && r.iy == 0.0f && r.iz == 0.0f) != 0ull) {
+    if (act == 0ull || __builtin_amdgcn_ballot_w64(active && r.ix() == 0.0f && r.iy() == 0.0f && r.iz() == 0.0f) != 0ull) {
         B.ilx = B.ihx = B.ily = B.ihy = B.ilz = B.ihz = 0.0f; B.mlx = B.mhx = B.mly = B.mhy = B.mlz = B.mhz = 0.0f;
     }
     B.amx = fmaxf(fabsf(B.ilx), fabsf(B.ihx)); B.amy = fmaxf(fabsf(B.ily), fabsf(B.ihy)); B.amz = fmaxf(fabsf(B.ilz), fabsf(B.ihz));
@@ -456,27 +503,35 @@ __device__ __forceinline__ uint32_t wave_compact2(bool keep, uint32_t a, uint32_
 __device__ __forceinline__ uint32_t lane_read(uint32_t v, uint32_t src_lane) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v); }
 
 // One cluster of an own list (the <= 8 slots from cb0) for the lane-filter kernel: per-triangle boxes (same conservative fp32 filter, one level
-// down), then only the triangles whose box some lane may hit are fetched (80-byte f64 records) and tested.  hc: this lane's ray may hit the cluster.
-__device__ __forceinline__ void own_cluster_lane(PROF_DECL const RRT_CONSTANT DevClusterBox* tboxes, const RRT_CONSTANT DevTriGeom* geom, uint32_t cb0, uint32_t cn, bool hc,
+// down), then only the triangles whose box some lane may hit are fetched (80-byte f64 records) and tested.
+__device__ __forceinline__ void own_cluster_lane(PROF_DECL const RRT_CONSTANT DevClusterBox* tboxes, const RRT_CONSTANT DevTriGeom* geom, uint32_t cb0, uint32_t cn,
                                                  const Ray32& r32, V3 o, V3 d, double& own_t, uint32_t& own_slot, uint32_t& own_pos) {
     const RRT_CONSTANT u32x16* tbx = (const RRT_CONSTANT u32x16*)(tboxes + cb0);
     uint32_t lane_tri = 0, wave_tri = 0;
-#define RRT_TB(i, v, off)                                                                                                          \
-    if (i < cn) {                                                                                                                  \
-        UBox B; B.cx = mkf(v[off]); B.cy = mkf(v[off + 1]); B.cz = mkf(v[off + 2]);                                             \
-        B.hx = mkf(v[off + 3]); B.hy = mkf(v[off + 4]); B.hz = mkf(v[off + 5]); B.a = 0; B.b = 0;                               \
-        const bool h = hc && slab32(B, r32);                                                                                      \
+#define RRT_TB(v, off)                                                                                                             \
+    {                                                                                                                              \
+        float tmin, tmax;                                                                                                          \
+        slab32_pk(sgpr_pair(v[off], v[off + 1]), sgpr_pair(v[off + 2], v[off + 3]), sgpr_pair(v[off + 4], v[off + 5]), r32, tmin, tmax);  \
         PROF_ADD(4, 1);                                                                                                            \
-        lane_tri |= h ? (1u << i) : 0u;                                                                                            \
-        wave_tri |= (__builtin_amdgcn_ballot_w64(h) != 0ull) ? (1u << i) : 0u;                                                     \
+        box_hit_shift(tmin, tmax, lane_tri, wave_tri);                                                                            \
     }
     {
+        // The last box first, results shifted in from below.
+        // (Lanes that missed the cluster's box are not masked out: a triangle's box lies inside its cluster's, so they miss here too bar rounding,
+        // and a lane that does slip through merely tests a triangle it cannot hit.)
         const u32x16 t01 = tbx[0], t23 = tbx[1];
-        RRT_TB(0u, t01, 0) RRT_TB(1u, t01, 8) RRT_TB(2u, t23, 0) RRT_TB(3u, t23, 8)
-    }
-    if (cn > 4u) {
-        const u32x16 t45 = tbx[2], t67 = tbx[3];
-        RRT_TB(4u, t45, 0) RRT_TB(5u, t45, 8) RRT_TB(6u, t67, 0) RRT_TB(7u, t67, 8)
+        if (cn > 4u) {
+            const u32x16 t45 = tbx[2], t67 = tbx[3];
+            if (cn > 7u) RRT_TB(t67, 8)
+            if (cn > 6u) RRT_TB(t67, 0)
+            if (cn > 5u) RRT_TB(t45, 8)
+            RRT_TB(t45, 0) RRT_TB(t23, 8) RRT_TB(t23, 0) RRT_TB(t01, 8) RRT_TB(t01, 0)
+        } else {
+            if (cn > 3u) RRT_TB(t23, 8)
+            if (cn > 2u) RRT_TB(t23, 0)
+            if (cn > 1u) RRT_TB(t01, 8)
+            RRT_TB(t01, 0)
+        }
     }
 #undef RRT_TB
     if (wave_tri) {
@@ -518,7 +573,7 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
     const RRT_CONSTANT DevClusterBox* cboxes = (const RRT_CONSTANT DevClusterBox*)own_sgprs(S.cboxes);
     const RRT_CONSTANT DevClusterBox* child_boxes = (const RRT_CONSTANT DevClusterBox*)own_sgprs(S.child_boxes);
     const RRT_CONSTANT DevClusterBox* tboxes = (const RRT_CONSTANT DevClusterBox*)own_sgprs(S.tboxes);
-    const Ray32 r32 = make_ray32(o, d, S.cull_limit, S.cull_enabled != 0 && filter_ok);   // filter_ok == false: this lane walks every list in full
+    const Ray32 r32 = make_ray32(o, d, S.cull_limit, S.cull_half_over_limit, S.cull_enabled != 0 && filter_ok);   // filter_ok == false: this lane walks every list in full
     // (lane-filter kernel only: with ~2 slab tests per walk on coherent frames the per-walk set-up costs the bundle-filter kernel what the
     // cheaper quotients save -- measured, rocprofv3 SQ_INSTS_VALU 502.8 M -> 495.6 M per teapot frame but 2 % slower; the soups gain 2 %)
     RayRcp RR; RR.rx = RR.ry = RR.rz = 0.0; RR.plain = false;
@@ -586,12 +641,23 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                         const RRT_CONSTANT u32x16* cbx = (const RRT_CONSTANT u32x16*)(child_boxes + (fc - 1u));
 #define RRT_CB(k, v, off)                                                                                                          \
                         if (fl & (1u << k)) {                                                                                      \
-                            UBox B; B.cx = mkf(v[off]); B.cy = mkf(v[off + 1]); B.cz = mkf(v[off + 2]);                         \
-                            B.hx = mkf(v[off + 3]); B.hy = mkf(v[off + 4]); B.hz = mkf(v[off + 5]); B.a = 0; B.b = 0;           \
-                            const bool h = slab32(B, r32);                                                                        \
+                            bool h;                                                                                                \
+                            if constexpr (kBundle) {                                                                               \
+                                UBox B; B.cx = mkf(v[off]); B.cy = mkf(v[off + 1]); B.cz = mkf(v[off + 2]);                     \
+                                B.hx = mkf(v[off + 3]); B.hy = mkf(v[off + 4]); B.hz = mkf(v[off + 5]); B.a = 0; B.b = 0;       \
+                                h = slab32(B, r32);                                                                               \
+                            } else {                                                                                               \
+                                float tmin, tmax;                                                                                  \
+                                slab32_pk(sgpr_pair(v[off], v[off + 1]), sgpr_pair(v[off + 2], v[off + 3]), sgpr_pair(v[off + 4], v[off + 5]), r32, tmin, tmax);  \
+                                h = tmin <= tmax;                                                                                  \
+                            }                                                                                                      \
                             lane_reach |= h ? (1u << k) : 0u;                                                                      \
                             reach |= (__builtin_amdgcn_ballot_w64(h) != 0ull) ? (1u << k) : 0u;                                                          \
                         }
+                        // (Children are often absent, so the results are OR-ed in at their own bit rather than shifted in as box_hit_shift does: the
+                        // zeros to shift in for absent children cost more than the shift saves.  Measured, teapot / 100 k soup / 1 M soup: the packed
+                        // arithmetic gains the lane-filter kernel 2 % on the soups and costs the bundle-filter kernel 4 % on the teapot -- register
+                        // pairs in a kernel that is short of VGPRs -- so each kernel gets the form that suits it.)
                         if (fl & 0x0Fu) { const u32x16 b01 = cbx[0], b23 = cbx[1]; RRT_CB(0, b01, 0) RRT_CB(1, b01, 8) RRT_CB(2, b23, 0) RRT_CB(3, b23, 8) }
                         if (fl & 0xF0u) { const u32x16 b45 = cbx[2], b67 = cbx[3]; RRT_CB(4, b45, 0) RRT_CB(5, b45, 8) RRT_CB(6, b67, 0) RRT_CB(7, b67, 8) }
 #undef RRT_CB
@@ -806,13 +872,14 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                 for (uint32_t si = 0; si < sc; ++si) {
                     UBox SN = SP;
                     if (si + 1 < sc) SN = load_ubox(supers + sb + si + 1);                            // scalar prefetch of the next super-cluster
-                    const bool hs = (sc == 1) || slab32(SP, r32);
+                    const bool hs = (sc == 1) || slab32_u(SP, r32);
+                    const unsigned long long hs_mask = __builtin_amdgcn_ballot_w64(hs);
                     const uint32_t tb = SP.a, tn = SP.b;
                     PROF_ADD(10, 1);
                     if constexpr (kGroups) {
                         if (sc > 1 && tn == 0u) {
                             // a group record (clusters.cpp): the box of the next `tb` super-clusters; if no lane can reach it they are all skipped
-                            if (__builtin_amdgcn_ballot_w64(hs) == 0ull) {
+                            if (hs_mask == 0ull) {
                                 si += tb;
                                 if (si + 1 < sc) SN = load_ubox(supers + sb + si + 1);
                             }
@@ -820,35 +887,40 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                             continue;
                         }
                     }
-                    if (__builtin_amdgcn_ballot_w64(hs) != 0ull) {
+                    if (hs_mask != 0ull) {
                         // the (up to) 8 cluster boxes of this super-cluster in bursts of 4; cluster c covers slots tb+8c .. tb+8c+7
                         const RRT_CONSTANT u32x16* cb = (const RRT_CONSTANT u32x16*)(cboxes + (tb >> 3));
                         const uint32_t nc = (tn + 7u) >> 3;
                         uint32_t lane_hits = 0, wave_hits = 0;
-#define RRT_CL(c, v, off)                                                                                                          \
-                        if (c < nc) {                                                                                          \
-                            UBox B; B.cx = mkf(v[off]); B.cy = mkf(v[off + 1]); B.cz = mkf(v[off + 2]);                     \
-                            B.hx = mkf(v[off + 3]); B.hy = mkf(v[off + 4]); B.hz = mkf(v[off + 5]); B.a = 0; B.b = 0;       \
-                            const bool h = hs && slab32(B, r32);                                                              \
+#define RRT_CL(v, off)                                                                                                             \
+                        {                                                                                                      \
+                            float tmin, tmax;                                                                                  \
+                            slab32_pk(sgpr_pair(v[off], v[off + 1]), sgpr_pair(v[off + 2], v[off + 3]), sgpr_pair(v[off + 4], v[off + 5]), r32, tmin, tmax);  \
                             PROF_ADD(11, 1);                                                                                   \
-                            lane_hits |= h ? (1u << c) : 0u;                                                                   \
-                            wave_hits |= (__builtin_amdgcn_ballot_w64(h) != 0ull) ? (1u << c) : 0u;                                                  \
+                            box_hit_shift(tmin, tmax, lane_hits, wave_hits);                                                  \
                         }
                         {
+                            // (as for the triangle boxes: no mask for the lanes that missed the super-cluster's box)
                             const u32x16 c01 = cb[0], c23 = cb[1];
-                            RRT_CL(0u, c01, 0) RRT_CL(1u, c01, 8) RRT_CL(2u, c23, 0) RRT_CL(3u, c23, 8)
-                        }
-                        if (nc > 4u) {
-                            const u32x16 c45 = cb[2], c67 = cb[3];
-                            RRT_CL(4u, c45, 0) RRT_CL(5u, c45, 8) RRT_CL(6u, c67, 0) RRT_CL(7u, c67, 8)
+                            if (nc > 4u) {
+                                const u32x16 c45 = cb[2], c67 = cb[3];
+                                if (nc > 7u) RRT_CL(c67, 8)
+                                if (nc > 6u) RRT_CL(c67, 0)
+                                if (nc > 5u) RRT_CL(c45, 8)
+                                RRT_CL(c45, 0) RRT_CL(c23, 8) RRT_CL(c23, 0) RRT_CL(c01, 8) RRT_CL(c01, 0)
+                            } else {
+                                if (nc > 3u) RRT_CL(c23, 8)
+                                if (nc > 2u) RRT_CL(c23, 0)
+                                if (nc > 1u) RRT_CL(c01, 8)
+                                RRT_CL(c01, 0)
+                            }
                         }
 #undef RRT_CL
                         while (wave_hits) {
                             const uint32_t c = __builtin_ctz(wave_hits);
                             wave_hits &= wave_hits - 1u;
-                            const bool hc = (lane_hits >> c) & 1u;
                             const uint32_t cb0 = tb + 8u * c, cn = (tn - 8u * c < 8u) ? tn - 8u * c : 8u;
-                            own_cluster_lane(PROF_ARG tboxes, geom, cb0, cn, hc, r32, o, d, own_t, own_slot, own_pos);
+                            own_cluster_lane(PROF_ARG tboxes, geom, cb0, cn, r32, o, d, own_t, own_slot, own_pos);
                         }
                     }
                     SP = SN;
@@ -964,7 +1036,7 @@ __device__ __forceinline__ void traverse_ray(PROF_DECL const DevScene& S, const 
     double ret_t = kInf; uint32_t ret_slot = kNone;
     const DevNode* nodes = S.nodes; const DevTriGeom* geom = S.geom; const DevSuper* supers = S.supers;
     const DevClusterBox* cboxes = S.cboxes; const DevClusterBox* child_boxes = S.child_boxes; const DevClusterBox* tboxes = S.tboxes;
-    const Ray32 r32 = make_ray32(o, d, S.cull_limit, S.cull_enabled != 0 && filter_ok);
+    const Ray32 r32 = make_ray32(o, d, S.cull_limit, S.cull_half_over_limit, S.cull_enabled != 0 && filter_ok);
     const RayRcp RR = make_ray_rcp(o, d, S.bounds_plain != 0);
     PROF_ADD(6, 1); PROF_ADD(7, __popcll(__ballot(active)));
     PROF_T(5);
