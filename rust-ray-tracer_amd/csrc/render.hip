@@ -1254,17 +1254,8 @@ __device__ __forceinline__ uint32_t trace_colour(PROF_DECL const DevScene& S, co
     while (__any(live)) {
         double t; uint32_t slot;
         PROF_T(4);                                                       // [4] shading / state machine between traversals
-#ifdef RRT_MIXED_POLICY   /* developer experiment: kWalkRay instantiation runs the lane walk for some traversals */
-        if constexpr (kWalk == kWalkRay) {
-            const unsigned long long lv = __builtin_amdgcn_ballot_w64(live), sh = __builtin_amdgcn_ballot_w64(live && in_shadow);
-            const bool use_ray = (RRT_MIXED_POLICY == 1) ? (2 * __popcll(sh) >= __popcll(lv)) : (2 * __popcll(sh) < __popcll(lv));
-            if (use_ray) traverse_ray<kGroups>(PROF_ARG S, stk, live, in_shadow, !(first_unfiltered && depth == 0u && !in_shadow), ro, rd, rmax, t, slot);
-            else traverse<false, kGroups>(PROF_ARG S, stk, live, in_shadow, !(first_unfiltered && depth == 0u && !in_shadow), ro, rd, rmax, t, slot);
-        } else
-#else
         if constexpr (kWalk == kWalkRay) traverse_ray<kGroups>(PROF_ARG S, stk, live, in_shadow, !(first_unfiltered && depth == 0u && !in_shadow), ro, rd, rmax, t, slot);
         else
-#endif
         traverse<kWalk == kWalkBundle, kGroups>(PROF_ARG S, stk, live, in_shadow, !(first_unfiltered && depth == 0u && !in_shadow), ro, rd, rmax, t, slot);
         if (live) {
             const bool found = slot != kNone;

@@ -84,3 +84,12 @@ def test_round2_entry_points_validate_their_arguments_without_a_gpu(rrt, teapot)
     assert L.rrt_get_setup_times(teapot._h, None, C.byref(t)) == rrt.OK
     assert t.parse_ms > 0 and t.texture_ms > 0 and t.octree_ms > 0 and t.index_ms == 0 and t.upload_ms == 0
     assert L.rrt_get_setup_times(None, None, None) == rrt.ERR_INVALID_ARG
+
+
+def test_flag_constants_match_the_header(rrt):
+    """The Python mirror's RRT_FLAG_* values are the header's (a forced traversal variant is requested by flag)."""
+    import re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "rrt.h")).read()
+    vals = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define RRT_FLAG_(\w+) (\d+)u", hdr)}
+    assert vals == {"NO_CULL": rrt.FLAG_NO_CULL, "LANE_FILTER": rrt.FLAG_LANE_FILTER, "BUNDLE_FILTER": rrt.FLAG_BUNDLE_FILTER, "RAY_WALK": rrt.FLAG_RAY_WALK}
+    assert rrt.VARIANT_NAMES == ("lane", "bundle", "ray")

@@ -466,3 +466,29 @@ def test_bench_multi_gpu_choreography_single_rank():
     assert single["n_gpus"] == 1 and single["unit"] == "Mrays/s"
     assert inlib["gather"] == "lib" and piped["gather"] == "torch" and inlib["pipeline_fallback"] is False and inlib["gather_ms"] is not None
     assert "frame_ms_host_fb" in single and single["host_fb"]["identical_to_device_frame"] and "setup_ms" in single
+
+
+@pytest.mark.gpu
+def test_per_ray_entry_points_pick_their_own_variant(rrt, teapot):
+    """rrt_intersect_rays / rrt_get_ray_colours measure the three traversal variants on the first large batch and keep the fastest (scattered rays:
+    the ray walk, up to 3x faster than the node-coherent walks); whatever is picked, results are those of the exact mode, and a forced variant
+    is used as is.  rrt_last_stats reports the kernel time and the variant of the per-ray launch."""
+    rng = np.random.default_rng(23)
+    n = 1 << 16
+    o = rng.uniform([-5, -0.5, -8], [5, 6, 5], (n, 3)); d = rng.normal(size=(n, 3))
+    exact = rrt.RayTracer(teapot, rrt.default_lights(), no_cull=True)
+    ref = exact.intersect_rays(o, d)
+    auto = rrt.RayTracer(teapot, rrt.default_lights())
+    small = auto.intersect_rays(o[:1000], d[:1000])                      # below the tuning threshold: the frame variant (none measured yet: lane)
+    assert auto.last_stats()["filter_variant"] == 0
+    for x, y in zip(small, ref): assert np.array_equal(x, y[:1000])
+    got = auto.intersect_rays(o, d)
+    st = auto.last_stats()
+    assert st["filter_variant"] in (0, 1, 2) and st["kernel_ms"] > 0 and st["width"] == n
+    picked = st["filter_variant"]
+    for x, y in zip(got, ref): assert np.array_equal(x, y)
+    assert np.array_equal(auto.get_ray_colours(o[:20000], d[:20000]), exact.get_ray_colours(o[:20000], d[:20000]))
+    assert auto.last_stats()["filter_variant"] == picked                 # measured once per raytracer
+    forced = rrt.RayTracer(teapot, rrt.default_lights(), box_filter="bundle")
+    for x, y in zip(forced.intersect_rays(o, d), ref): assert np.array_equal(x, y)
+    assert forced.last_stats()["filter_variant"] == 1

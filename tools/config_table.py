@@ -20,7 +20,7 @@ def run(name, path, w, h, compare=True):
         ex = rrt.RayTracer(sd, rrt.default_lights(), no_cull=True)
         same = bool(np.array_equal(ex.render(w, h), fb)); t_ex = ex.last_stats()["kernel_ms"]
     row = dict(config=name, tris=sd.info["n_tris"], nodes=sd.info["n_nodes"], size=f"{w}x{h}", kernel_ms=round(float(np.median(ts)), 3),
-               mrays_primary=round(st["rays_primary"] / np.median(ts) / 1e3, 1), filter="bundle" if st["filter_variant"] else "lane",
+               mrays_primary=round(st["rays_primary"] / np.median(ts) / 1e3, 1), filter=rrt.VARIANT_NAMES[st["filter_variant"]],
                identical_to_no_cull=same, no_cull_ms=round(t_ex, 2) if compare else None)
     rows.append(row); print(json.dumps(row), flush=True)
 run("teapot 640x480 (configs[0] scene)", os.path.join(A, "model2.obj"), 640, 480)
