@@ -58,7 +58,7 @@ typedef struct { const uint8_t *rgb; uint32_t width, height; } rrt_texture;
 #define RRT_FLAG_NO_CULL 1u
 /* The index boxes are tested either by every ray against one box at a time (LANE filter) or by 64 boxes at a time against the wave's ray
  * bundle (BUNDLE filter; faster on coherent rays, slower on scattered ones).  Both give the same pixels.  By default the first frame of
- * every new frame size is rendered with both (a one-off stream synchronisation) and the faster is kept for that size; these flags force one. */
+ * every new frame size is rendered with every variant (a one-off stream synchronisation) and the fastest is kept for that size; these flags force one. */
 #define RRT_FLAG_LANE_FILTER 2u
 #define RRT_FLAG_BUNDLE_FILTER 4u
 /* Both of the above walk the octree node-coherently (one node per wave step, records in scalar registers): right for rays that share nodes.
@@ -186,7 +186,10 @@ typedef void (*rrt_update_fn)(void *user, const uint32_t *fb, uint32_t width, ui
 int rrt_render_progressive(rrt_raytracer *rt, uint32_t width, uint32_t height, uint32_t *out_fb, uint32_t chunk_rows,
                            rrt_update_fn on_update, void *user);
 
-/* Batched RayTracer::get_ray_colour (raytracer.rs:29): n rays, origins/dirs [n][3] host doubles -> colours[n] 0x00RRGGBB. */
+/* Batched RayTracer::get_ray_colour (raytracer.rs:29): n rays, origins/dirs [n][3] host doubles -> colours[n] 0x00RRGGBB.
+ * The two per-ray entry points take whatever rays the caller has, so unless a variant is forced they pick theirs by measurement too: the first batch of
+ * at least 16384 rays is timed with all three variants on its first 65536 rays and the fastest is kept for later calls (smaller batches before that
+ * run the frame variant).  rrt_last_stats after a per-ray call: kernel_ms and filter_variant of that launch, width = n, height = 1. */
 int rrt_get_ray_colours(rrt_raytracer *rt, uint32_t n, const double *origins, const double *dirs, uint32_t *colours);
 
 /* Batched Ray::intersect_with_octant_with_max_t(octree, 0, max_t) (ray.rs:104-168): hit[n] 0/1, t,u,v [n], tri[n] = index in
