@@ -35,7 +35,8 @@ sys.path.insert(0, ROOT)
 
 FP64_VECTOR_PEAK_TFLOPS = 78.6     # MI355X f64 vector (non-matrix) peak: 256 CU x 128 FLOP/clk x 2.4 GHz (FMA = 2 FLOP); = 1/2 of the fp32 vector 157.3 TF in MI355X_MICROARCH.md
 HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-KERNEL_SOURCES = ("rust-ray-tracer_amd/csrc/render.hip", "rust-ray-tracer_amd/csrc/clusters.cpp", "rust-ray-tracer_amd/csrc/device_scene.hpp")
+KERNEL_SOURCES = ("rust-ray-tracer_amd/csrc/render.hip", "rust-ray-tracer_amd/csrc/clusters.cpp", "rust-ray-tracer_amd/csrc/device_scene.hpp",
+                  "rust-ray-tracer_amd/csrc/Makefile")   # the Makefile carries the code-generation switches the kernels are built with
 
 
 def kernel_source_sha256() -> str:

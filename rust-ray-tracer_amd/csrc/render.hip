@@ -29,6 +29,16 @@
 
 #include "device_scene.hpp"
 
+// The library compiles this file TWICE (csrc/Makefile): -DRRT_TU=1 = the frame kernels (render_kernel, detile_kernel) and their launchers,
+// -DRRT_TU=2 = the per-ray kernels (ray_colour_kernel, intersect_kernel) -- same device functions, different code-generation switches (the frame
+// kernels are issue-bound and want the max-ILP scheduler, which costs the per-ray kernels on scattered rays 17 %).  Without RRT_TU: everything
+// (developer builds, tools).
+#ifndef RRT_TU
+#define RRT_TU 0
+#endif
+#define RRT_TU_FRAME (RRT_TU != 2)
+#define RRT_TU_RAYS (RRT_TU != 1)
+
 namespace rrt {
 namespace {
 
@@ -1391,6 +1401,7 @@ __device__ __forceinline__ uint32_t trace_colour(PROF_DECL const DevScene& S, co
 #ifndef RRT_WAVES_RAY
 #define RRT_WAVES_RAY 4
 #endif
+#if RRT_TU_FRAME
 template <int kWalk, bool kGroups>
 __global__ __launch_bounds__(64, kWalk == kWalkBundle ? RRT_WAVES_BUNDLE : kWalk == kWalkLane ? RRT_WAVES_LANE : RRT_WAVES_RAY) void render_kernel(const DevScene S, const FrameParams F, uint32_t* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -1446,7 +1457,9 @@ __global__ __launch_bounds__(256) void detile_kernel(uint32_t width, uint32_t he
     const uint32_t r = tile % world, lt = tile / world;
     fb[i] = gathered[((size_t)r * tiles_per_rank + lt) * 64 + ((py & 7u) * 8 + (px & 7u))];
 }
+#endif   // RRT_TU_FRAME
 
+#if RRT_TU_RAYS
 template <int kWalk>
 __global__ __launch_bounds__(64) void ray_colour_kernel(const DevScene S, uint32_t n, const double* __restrict__ origins, const double* __restrict__ dirs,
                                                         uint32_t* __restrict__ colours) {
@@ -1484,9 +1497,11 @@ __global__ __launch_bounds__(64) void intersect_kernel(const DevScene S, uint32_
     mt_full(S.geom + slot, o, d, t2, u, v);
     hit[i] = 1; t_out[i] = t; u_out[i] = u; v_out[i] = v; tri_out[i] = S.attr[slot].orig;
 }
+#endif   // RRT_TU_RAYS
 
 }  // namespace
 
+#if RRT_TU_FRAME
 // Forces the code object of this library onto the current device (HIP loads it lazily, ~80 ms for these kernels): called from a helper thread
 // while the host is still parsing the scene (api.cpp, warm_device_async).
 void preload_kernels() {
@@ -1569,6 +1584,9 @@ int launch_detile(uint32_t width, uint32_t height, uint32_t world, const uint32_
     return (int)hipGetLastError();
 }
 
+#endif   // RRT_TU_FRAME
+
+#if RRT_TU_RAYS
 int launch_ray_colours(const DevScene& s, uint32_t n, const double* d_origins, const double* d_dirs, uint32_t* d_colours, void* stream, int walk) {
     if (n == 0) return 0;
     const dim3 grid((n + 63) / 64), block(64);
@@ -1589,5 +1607,6 @@ int launch_intersect(const DevScene& s, uint32_t n, const double* d_origins, con
     else hipLaunchKernelGGL(intersect_kernel<kWalkLane>, grid, block, lds, (hipStream_t)stream, s, n, d_origins, d_dirs, d_max_t, d_hit, d_t, d_u, d_v, d_tri);
     return (int)hipGetLastError();
 }
+#endif   // RRT_TU_RAYS
 
 }  // namespace rrt

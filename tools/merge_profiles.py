@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import kernel_source_sha256
 sha = kernel_source_sha256()
-out = {"source_sha256": sha, "sources": ["rust-ray-tracer_amd/csrc/render.hip", "rust-ray-tracer_amd/csrc/clusters.cpp", "rust-ray-tracer_amd/csrc/device_scene.hpp"], "workloads": {}}
+out = {"source_sha256": sha, "sources": list(__import__("bench").KERNEL_SOURCES), "workloads": {}}
 for arg in sys.argv[1:]:
     key, path = arg.split("=", 1)
     s = json.load(open(path))
