@@ -4,5 +4,5 @@
 set -e
 cd "$(dirname "$0")/../rust-ray-tracer_amd/csrc"
 NAME=$1; EXTRA=$2; RENDER=${3:-render.hip}
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math ${KFLAGS--mllvm -disable-machine-licm -mllvm -amdgpu-sched-strategy=max-ilp -mllvm -simplifycfg-sink-common=false -mllvm -enable-pre=false} -I. $EXTRA -shared -o ../librrt_hip_$NAME.so api.cpp octree.cpp clusters.cpp obj_loader.cpp image_decode.cpp $RENDER -lz 2>/dev/null
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math ${KFLAGS--mllvm -disable-machine-licm -mllvm -amdgpu-sched-strategy=max-ilp -mllvm -simplifycfg-sink-common=false -mllvm -enable-pre=false -mllvm -join-splitedges} -I. $EXTRA -shared -o ../librrt_hip_$NAME.so api.cpp octree.cpp clusters.cpp obj_loader.cpp image_decode.cpp $RENDER -lz 2>/dev/null
 echo built librrt_hip_$NAME.so
