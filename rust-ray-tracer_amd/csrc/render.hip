@@ -293,8 +293,8 @@ __device__ __forceinline__ Ray32 make_ray32(V3 o, V3 d, float limit, float half_
     const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z, dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
     const float dmax = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
     // (dmax > 1e-10: a component below 1e-20 is treated as parallel, which is only right while the ray cannot cross the scene -- t <= 2 limit / dmax -- by
-    // moving along that axis)
-    const bool cull = enabled && fabsf(ox) < limit && fabsf(oy) < limit && fabsf(oz) < limit && dmax < limit && dmax > 1e-10f;
+    // moving along that axis; dmax < 1e8: the parallel axes' slab values are bounded by 1.25e30 dmax and must stay finite)
+    const bool cull = enabled && fabsf(ox) < limit && fabsf(oy) < limit && fabsf(oz) < limit && dmax < limit && dmax > 1e-10f && dmax < 1e8f;
     const float sigma = cull ? dmax * half_over_limit : 0.0f;
     // v_rcp_f32 (1 ulp) is plenty for a filter whose boxes are padded by ~1e-5 of the scene: an IEEE divide would cost ten instructions each
     const float ix = !cull ? 0.0f : (fabsf(dx) < 1e-20f ? 1e30f : __builtin_amdgcn_rcpf(dx)) * sigma;

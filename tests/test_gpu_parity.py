@@ -492,3 +492,23 @@ def test_per_ray_entry_points_pick_their_own_variant(rrt, teapot):
     forced = rrt.RayTracer(teapot, rrt.default_lights(), box_filter="bundle")
     for x, y in zip(forced.intersect_rays(o, d), ref): assert np.array_equal(x, y)
     assert forced.last_stats()["filter_variant"] == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scale", [1e-13, 1e-9, 1e6, 1e9, 1e12])
+def test_direction_magnitude_does_not_matter_to_the_index(rrt, teapot, scale):
+    """The reference never normalises a direction (t simply scales inversely), so rays with tiny or huge direction vectors -- some with exactly zero
+    components, which the fp32 filter treats as parallel to their slabs -- must give the same triangle and (u, v) with the index as without it, and
+    the same as the unscaled rays; t scales by 1/scale up to rounding.  (Directions beyond the filter's working range run unfiltered.)"""
+    rng = np.random.default_rng(31)
+    n = 20000
+    o = rng.uniform([-5, -0.5, -8], [5, 6, 5], (n, 3)); d = rng.normal(size=(n, 3))
+    d[:3000, rng.integers(0, 3, 3000)] *= 0.0                              # (fancy indexing: zero one random component of the first 3000 rays)
+    d[np.arange(3000), rng.integers(0, 3, 3000)] = 0.0
+    exact = rrt.RayTracer(teapot, rrt.default_lights(), no_cull=True)
+    ref = exact.intersect_rays(o, d * scale)
+    base = exact.intersect_rays(o, d)
+    assert np.array_equal(ref[0], base[0]) or scale in (1e-13, 1e12)        # (at the extremes t > eps / a within eps may flip a few borderline hits)
+    for mode in ("lane", "bundle", "ray"):
+        got = rrt.RayTracer(teapot, rrt.default_lights(), box_filter=mode).intersect_rays(o, d * scale)
+        for x, y in zip(got, ref): assert np.array_equal(x, y), (mode, scale)
