@@ -87,7 +87,7 @@ def main() -> None:
                     "gather and de-tiling behind the C ABI); `torch` = the same choreography issued from here with torch.distributed.gather; `auto` = K steps of each, "
                     "torch first, the library under a watchdog, the faster one reported (both in `gather_paths`)")
     ap.add_argument("--lib-timeout", type=float, default=120.0, help="--gather auto: seconds the library path may take before the torch result is reported alone")
-    ap.add_argument("--walk", choices=("auto", "lane", "bundle", "ray"), default="auto", help="traversal variant: auto = the library measures all three on the first frame (the product default); the others force one (developer A/B)")
+    ap.add_argument("--walk", choices=("auto", "lane", "bundle", "ray"), default="auto", help="traversal variant: auto = the library measures all three on the second frame of a size (the product default); the others force one (developer A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-fb", action="store_true", help="skip the boundary-inclusive rrt_render timings (frame_ms_host_fb)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the bounded cpu_baseline leg (3 samples)")

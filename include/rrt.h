@@ -57,13 +57,14 @@ typedef struct { const uint8_t *rgb; uint32_t width, height; } rrt_texture;
  * rays are not.  Tests compare the two modes bit for bit on every config and on 10^6 constructed near-coplanar rays. */
 #define RRT_FLAG_NO_CULL 1u
 /* The index boxes are tested either by every ray against one box at a time (LANE filter) or by 64 boxes at a time against the wave's ray
- * bundle (BUNDLE filter; faster on coherent rays, slower on scattered ones).  Both give the same pixels.  By default the first frame of
- * every new frame size is rendered with every variant (a one-off stream synchronisation) and the fastest is kept for that size; these flags force one. */
+ * bundle (BUNDLE filter; faster on coherent rays, slower on scattered ones).  Both give the same pixels.  By default the first frame of a frame
+ * size runs the variant a rule of thumb picks (the reference renders one frame per run: it pays nothing extra), and a SECOND frame of the same size
+ * is first rendered with every variant (a one-off stream synchronisation), the fastest being kept for that size; these flags force one. */
 #define RRT_FLAG_LANE_FILTER 2u
 #define RRT_FLAG_BUNDLE_FILTER 4u
 /* Both of the above walk the octree node-coherently (one node per wave step, records in scalar registers): right for rays that share nodes.
  * RAY_WALK lets every ray of a wave visit its own node in every step (records through vector memory): right for scattered rays (large soups,
- * mirror bounces).  Same pixels again; the default measures all three on the first frame of a size. */
+ * mirror bounces).  Same pixels again; the default measures all three on the second frame of a size. */
 #define RRT_FLAG_RAY_WALK 8u
 
 /* Render constants that the reference hard-codes; NULL => these defaults. */

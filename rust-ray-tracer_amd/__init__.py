@@ -280,7 +280,7 @@ class RayTracer:
                  surface_offset: float = 0.0001, max_reflection_depth: int = 5, viewport=(1.0, 1.0, 1.0), no_cull: bool = False,
                  box_filter: Optional[str] = None):
         """no_cull=True (RRT_FLAG_NO_CULL): walk every own list in full, in list order, as ray.rs:119-129; default uses the cluster boxes.
-        box_filter: None = measured on the first frame, "lane" / "bundle" / "ray" = forced (RRT_FLAG_LANE_FILTER / RRT_FLAG_BUNDLE_FILTER /
+        box_filter: None = rule of thumb on the first frame of a size, measured on the second, "lane" / "bundle" / "ray" = forced (RRT_FLAG_LANE_FILTER / RRT_FLAG_BUNDLE_FILTER /
         RRT_FLAG_RAY_WALK); same pixels."""
         self.scene_data, self.lights, self.origin, self.device = scene_data, list(lights), origin, device
         cl = (CLight * max(1, len(self.lights)))()

@@ -42,7 +42,9 @@ struct rrt_raytracer {
     size_t staging_bytes = 0;
     static constexpr int kCopyChunks = 8;
     hipEvent_t chunk_ev[kCopyChunks] = {};
-    uint32_t tuned_w = 0, tuned_h = 0, tuned_world = 0;
+    uint32_t tuned_w = 0, tuned_h = 0, tuned_world = 0;   // frame size the variant below belongs to
+    uint32_t size_frames = 0;        // frames rendered at that size so far
+    bool size_measured = false;      // ... and whether the variants have been timed on it (second frame of a size)
 };
 
 namespace rrt {
@@ -158,11 +160,21 @@ void check_frame(const rrt_raytracer* rt, uint32_t width, uint32_t height) {
     if (width == 0 || height == 0 || (uint64_t)width * height > 0x7FFFFFFFull) throw Error{RRT_ERR_INVALID_ARG, "bad frame size"};
 }
 
-// Both filter variants produce identical pixels; which is faster depends on how coherent the rays of a wave are (scene, camera, frame size).
-// So the first frame of every new frame size is rendered with both (each twice: the first run warms caches) on the caller's buffer and
-// stream, timed with HIP events, and the faster one is kept for that size.  This synchronises the stream once per new size.
+// All traversal variants produce identical pixels; which is faster depends on how coherent the rays of a wave are (scene, camera, frame size).
+// The reference renders ONE frame per run, so the first frame of a size costs nothing extra: it runs the variant a rule of thumb picks (node-coherent
+// walk, bundle filter for small scenes -- their rays share the few upper nodes -- lane filter for large ones).  A caller that comes back for a SECOND
+// frame of the same size is rendering repeatedly, and that frame is first rendered with every variant (each twice: the first run warms caches) on the
+// caller's buffer and stream, timed with HIP events; the fastest is kept for that size.  This synchronises the stream once per size.
 void tune_variant(rrt_raytracer* rt, const FrameParams& f, uint32_t* d_out, void* stream) {
-    if (rt->variant_forced || (rt->tuned_w == f.width && rt->tuned_h == f.height && rt->tuned_world == f.world)) return;
+    if (rt->variant_forced) return;
+    if (!(rt->tuned_w == f.width && rt->tuned_h == f.height && rt->tuned_world == f.world)) {
+        rt->tuned_w = f.width; rt->tuned_h = f.height; rt->tuned_world = f.world;
+        rt->size_frames = 0; rt->size_measured = false;
+        rt->walk = rt->scene.n_slots < 50000u ? 1 : 0;
+    }
+    if (rt->size_measured) return;
+    if (++rt->size_frames < 2) return;
+    rt->size_measured = true;
     constexpr int kVariants = 3;
     float ms[kVariants] = {0, 0, 0};
     if (f.world == 1) {
@@ -195,7 +207,6 @@ void tune_variant(rrt_raytracer* rt, const FrameParams& f, uint32_t* d_out, void
     }
     rt->walk = 0;
     for (int variant = 1; variant < kVariants; variant++) if (ms[variant] < ms[rt->walk]) rt->walk = variant;
-    rt->tuned_w = f.width; rt->tuned_h = f.height; rt->tuned_world = f.world;
 }
 
 // The per-ray entry points take whatever rays the caller has: a coherent pixel grid or rays in all directions, and the three traversal variants are
