@@ -20,7 +20,9 @@ import collections, json, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "rust-ray-tracer_amd", "csrc")
 LLVM = "/opt/rocm/lib/llvm/bin"
-FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-simplifycfg-sink-common=false", "-mllvm", "-enable-pre=false", "-mllvm", "-join-splitedges"]   # the product's FLAGS + KFLAGS (csrc/Makefile)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _kflags import kflags
+FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", *kflags()]   # the product's FLAGS + KFLAGS (csrc/Makefile)
 HSACO = os.path.join(ROOT, "rust-ray-tracer_amd", "render_bbprof.hsaco")
 MAP = os.path.join(ROOT, "gpurun_out", "bbprof_map.json")
 COUNTS = os.path.join(ROOT, "gpurun_out", "bbprof_counts.txt")

@@ -3,7 +3,9 @@
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "rust-ray-tracer_amd", "csrc")
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-simplifycfg-sink-common=false", "-mllvm", "-enable-pre=false", "-mllvm", "-join-splitedges", "-S", "--cuda-device-only", "-o", "/tmp/render.gfx950.s",
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _kflags import kflags
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", *kflags(), "-S", "--cuda-device-only", "-o", "/tmp/render.gfx950.s",
        os.path.join(src, "render.hip"), "-Rpass-analysis=kernel-resource-usage"] + sys.argv[1:]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 keep = ("VGPRs", "TotalSGPRs", "ScratchSize [bytes/lane]", "Occupancy [waves/SIMD]", "SGPRs Spill", "VGPRs Spill")
