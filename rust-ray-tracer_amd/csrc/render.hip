@@ -29,15 +29,18 @@
 
 #include "device_scene.hpp"
 
-// The library compiles this file TWICE (csrc/Makefile): -DRRT_TU=1 = the frame kernels (render_kernel, detile_kernel) and their launchers,
-// -DRRT_TU=2 = the per-ray kernels (ray_colour_kernel, intersect_kernel) -- same device functions, different code-generation switches (the frame
-// kernels are issue-bound and want the max-ILP scheduler, which costs the per-ray kernels on scattered rays 17 %).  Without RRT_TU: everything
-// (developer builds, tools).
+// The library compiles this file THREE times (csrc/Makefile), same device functions, different code-generation switches per group of kernels:
+//   -DRRT_TU=1  the bundle-filter frame kernel, detile_kernel and the launchers (issue-bound: max-ILP scheduler);
+//   -DRRT_TU=3  the lane-filter and ray-walk frame kernels (as 1, plus the structurizer / load-store-vectorizer switches that gain the 1 M soup 5 %
+//               and cost the bundle-filter kernel 2.6 % on the teapot);
+//   -DRRT_TU=2  the per-ray kernels ray_colour_kernel, intersect_kernel (default scheduler: max-ILP costs scattered rays 17 %).
+// Without RRT_TU: everything in one unit (developer builds, tools).
 #ifndef RRT_TU
 #define RRT_TU 0
 #endif
-#define RRT_TU_FRAME (RRT_TU != 2)
-#define RRT_TU_RAYS (RRT_TU != 1)
+#define RRT_TU_FRAME (RRT_TU == 0 || RRT_TU == 1)      /* bundle-filter render kernel, detile, launch_render, preload */
+#define RRT_TU_LANE (RRT_TU == 0 || RRT_TU == 3)       /* lane-filter and ray-walk render kernels */
+#define RRT_TU_RAYS (RRT_TU == 0 || RRT_TU == 2)
 
 namespace rrt {
 namespace {
@@ -1389,11 +1392,11 @@ __device__ __forceinline__ uint32_t trace_colour(PROF_DECL const DevScene& S, co
 
 // ------------------------------------------------------------------------------------------------ kernels
 // One wave per workgroup; workgroup b renders quadrant (b & 3) of this rank's local tile (b >> 2).
-// Waves per SIMD (register budget) per filter variant, measured on MI355X: the lane-filter kernel runs best at 5 (96 VGPRs; scattered-ray scenes
-// need the latency hiding), the bundle-filter kernel equally fast at 4 and 5 -- 4 (128 VGPRs) spills far less (HBM traffic 1.3 GB vs 4.1 GB per
-// 1080p frame; the shading state that is cold during a walk is what spills).
+// Waves per SIMD (register budget) per traversal variant, measured on MI355X with the code-generation switches of the Makefile: 4 everywhere
+// (128 VGPRs).  The lane-filter kernel ran best at 5 (96 VGPRs) until its spills were cut down; now 4 is 2 % faster on both soups (12.3 -> 12.1 ms,
+// 28.2 -> 27.7 ms) and 6 is 20 % slower.  The bundle-filter kernel: 3 -> +20 %, 5 -> +11 %.  The ray walk: 3 -> +11 %, 5 -> +21 %.
 #ifndef RRT_WAVES_LANE
-#define RRT_WAVES_LANE 5
+#define RRT_WAVES_LANE 4
 #endif
 #ifndef RRT_WAVES_BUNDLE
 #define RRT_WAVES_BUNDLE 4
@@ -1401,7 +1404,7 @@ __device__ __forceinline__ uint32_t trace_colour(PROF_DECL const DevScene& S, co
 #ifndef RRT_WAVES_RAY
 #define RRT_WAVES_RAY 4
 #endif
-#if RRT_TU_FRAME
+#if RRT_TU_FRAME || RRT_TU_LANE
 template <int kWalk, bool kGroups>
 __global__ __launch_bounds__(64, kWalk == kWalkBundle ? RRT_WAVES_BUNDLE : kWalk == kWalkLane ? RRT_WAVES_LANE : RRT_WAVES_RAY) void render_kernel(const DevScene S, const FrameParams F, uint32_t* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -1448,6 +1451,8 @@ __global__ __launch_bounds__(64, kWalk == kWalkBundle ? RRT_WAVES_BUNDLE : kWalk
     }
 }
 
+#endif   // RRT_TU_FRAME || RRT_TU_LANE
+#if RRT_TU_FRAME
 __global__ __launch_bounds__(256) void detile_kernel(uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t world, uint32_t tiles_per_rank,
                                                      const uint32_t* __restrict__ gathered, uint32_t* __restrict__ fb) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1504,12 +1509,13 @@ __global__ __launch_bounds__(64) void intersect_kernel(const DevScene S, uint32_
 #if RRT_TU_FRAME
 // Forces the code object of this library onto the current device (HIP loads it lazily, ~80 ms for these kernels): called from a helper thread
 // while the host is still parsing the scene (api.cpp, warm_device_async).
+void preload_kernels_lane_ray();
+int launch_render_lane_ray(const DevScene& s, const FrameParams& f, uint32_t* d_out, void* stream, int walk, uint32_t n_blocks, uint32_t lds);
 void preload_kernels() {
     hipFuncAttributes a;
     (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&render_kernel<kWalkBundle, false>));
-    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&render_kernel<kWalkLane, false>));
-    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&render_kernel<kWalkRay, false>));
     (void)hipGetLastError();
+    preload_kernels_lane_ray();
 }
 
 uint32_t stack_bytes_per_wave(uint32_t levels) { return kParkBytes + levels * kLevelBytes; }
@@ -1562,16 +1568,9 @@ int launch_render(const DevScene& s, const FrameParams& f, uint32_t* d_out, void
     const dim3 grid(local_tiles * 4), block(64);
     const uint32_t lds = stack_bytes_per_wave(s.stack_levels);
     const hipStream_t q = (hipStream_t)stream;
-    if (walk == kWalkBundle) {
-        if (s.has_groups) hipLaunchKernelGGL((render_kernel<kWalkBundle, true>), grid, block, lds, q, s, f, d_out);
-        else hipLaunchKernelGGL((render_kernel<kWalkBundle, false>), grid, block, lds, q, s, f, d_out);
-    } else if (walk == kWalkRay) {
-        if (s.has_groups) hipLaunchKernelGGL((render_kernel<kWalkRay, true>), grid, block, lds, q, s, f, d_out);
-        else hipLaunchKernelGGL((render_kernel<kWalkRay, false>), grid, block, lds, q, s, f, d_out);
-    } else {
-        if (s.has_groups) hipLaunchKernelGGL((render_kernel<kWalkLane, true>), grid, block, lds, q, s, f, d_out);
-        else hipLaunchKernelGGL((render_kernel<kWalkLane, false>), grid, block, lds, q, s, f, d_out);
-    }
+    if (walk != kWalkBundle) return launch_render_lane_ray(s, f, d_out, stream, walk, local_tiles * 4, lds);
+    if (s.has_groups) hipLaunchKernelGGL((render_kernel<kWalkBundle, true>), grid, block, lds, q, s, f, d_out);
+    else hipLaunchKernelGGL((render_kernel<kWalkBundle, false>), grid, block, lds, q, s, f, d_out);
     return (int)hipGetLastError();
 }
 
@@ -1585,6 +1584,27 @@ int launch_detile(uint32_t width, uint32_t height, uint32_t world, const uint32_
 }
 
 #endif   // RRT_TU_FRAME
+
+#if RRT_TU_LANE
+void preload_kernels_lane_ray() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&render_kernel<kWalkLane, false>));
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&render_kernel<kWalkRay, false>));
+    (void)hipGetLastError();
+}
+int launch_render_lane_ray(const DevScene& s, const FrameParams& f, uint32_t* d_out, void* stream, int walk, uint32_t n_blocks, uint32_t lds) {
+    const dim3 grid(n_blocks), block(64);
+    const hipStream_t q = (hipStream_t)stream;
+    if (walk == kWalkRay) {
+        if (s.has_groups) hipLaunchKernelGGL((render_kernel<kWalkRay, true>), grid, block, lds, q, s, f, d_out);
+        else hipLaunchKernelGGL((render_kernel<kWalkRay, false>), grid, block, lds, q, s, f, d_out);
+    } else {
+        if (s.has_groups) hipLaunchKernelGGL((render_kernel<kWalkLane, true>), grid, block, lds, q, s, f, d_out);
+        else hipLaunchKernelGGL((render_kernel<kWalkLane, false>), grid, block, lds, q, s, f, d_out);
+    }
+    return (int)hipGetLastError();
+}
+#endif   // RRT_TU_LANE
 
 #if RRT_TU_RAYS
 int launch_ray_colours(const DevScene& s, uint32_t n, const double* d_origins, const double* d_dirs, uint32_t* d_colours, void* stream, int walk) {
