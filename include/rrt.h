@@ -66,6 +66,11 @@ typedef struct { const uint8_t *rgb; uint32_t width, height; } rrt_texture;
  * RAY_WALK lets every ray of a wave visit its own node in every step (records through vector memory): right for scattered rays (large soups,
  * mirror bounces).  Same pixels again; the default measures all three on the second frame of a size. */
 #define RRT_FLAG_RAY_WALK 8u
+/* Set-up.  By default rrt_raytracer_create builds everything the kernels read ON THE GPU from the uploaded triangle array: the octree exactly as
+ * Octree::push_triangle builds it one triangle at a time (octree.rs:41-241; level-parallel and order-exact, csrc/scene_build.hip), this build's index
+ * over the own lists, and the device records.  HOST_SETUP does the same on the host's cores (csrc/octree.cpp, clusters.cpp) and uploads the result:
+ * the two paths produce the same bytes in HBM (tests/test_gpu_build.py); the flag exists for that check and for A/B timing. */
+#define RRT_FLAG_HOST_SETUP 16u
 
 /* Render constants that the reference hard-codes; NULL => these defaults. */
 typedef struct {
@@ -97,8 +102,10 @@ typedef struct rrt_model rrt_model;
 
 /* parse_obj_file_lines (utils.rs:139-213) on the file at obj_path (read as main.rs:28); "mtllib"/texture names
  * resolve relative to the .obj's directory (the reference resolves against the cwd; it is run from its root).
- * Builds the octree incrementally in file order (utils.rs:192-198).  root = {min_x,max_x,min_y,max_y,min_z,max_z},
- * NULL => Octree::new(-20,20,-20,20,-20,20) (utils.rs:145). */
+ * root = {min_x,max_x,min_y,max_y,min_z,max_z}, NULL => Octree::new(-20,20,-20,20,-20,20) (utils.rs:145).
+ * The reference pushes every triangle into the octree as it parses (utils.rs:192-198).  Here the tree is built from the finished triangle list, in
+ * the same order, WHERE IT IS NEEDED: on the GPU by rrt_raytracer_create, or on the host the first time rrt_model_get_info / rrt_model_get_octree
+ * (or a RRT_FLAG_HOST_SETUP raytracer) asks for it.  RRT_ERR_DEPTH is therefore reported by those calls, not by the two loaders. */
 int rrt_model_load_obj(const char *obj_path, const double *root, rrt_model **out);
 
 /* For a host that already parsed the scene (the Rust host holds SceneData.triangles in push order):
@@ -198,12 +205,24 @@ int rrt_get_ray_colours(rrt_raytracer *rt, uint32_t n, const double *origins, co
 int rrt_intersect_rays(rrt_raytracer *rt, uint32_t n, const double *origins, const double *dirs, const double *max_t,
                        uint8_t *hit, double *t, double *u, double *v, uint32_t *tri);
 
+/* The octree of a raytracer whose set-up ran on the GPU (the default), read back from its device: same layout as rrt_model_get_octree; info (may be
+ * NULL) as rrt_model_get_info.  Any pointer may be NULL.  RRT_ERR_UNSUPPORTED for a RRT_FLAG_HOST_SETUP raytracer (ask the model). */
+int rrt_raytracer_get_octree(const rrt_raytracer *rt, rrt_model_info *info, double *aabb, uint32_t *first_child, uint32_t *tri_count,
+                             uint32_t *own_off, uint32_t *own_idx);
+/* Test / developer introspection: the bytes of one scene buffer in HBM.  out == NULL asks for the size only. */
+enum { RRT_BUF_NODES = 0, RRT_BUF_GEOM, RRT_BUF_ATTR, RRT_BUF_SUPERS, RRT_BUF_CBOXES, RRT_BUF_CHILD_BOXES, RRT_BUF_TBOXES, RRT_BUF_SUSPECTS,
+       RRT_BUF_OCT_BOX, RRT_BUF_OCT_FIRST_CHILD, RRT_BUF_OCT_TRI_COUNT, RRT_BUF_OCT_OWN_OFF, RRT_BUF_OCT_OWN_IDX, RRT_BUF_SLOT_TRI, RRT_BUF_SLOT_POS };
+int rrt_raytracer_get_buffer(const rrt_raytracer *rt, uint32_t which, void *out, size_t capacity, size_t *bytes);
+
 int rrt_last_stats(const rrt_raytracer *rt, rrt_stats *out);
-/* Wall time of the set-up stages that run once per scene (the reference does all of them inside parse_obj_file_lines, utils.rs:139-213,
- * before its one frame): model side = file read, .obj/.mtl parse, texture decode, octree build (octree.rs:41-241); raytracer side =
- * own-list index build (clusters.cpp) and upload to HBM; hip_init_ms = bringing the device's HIP context up at the start of rrt_raytracer_create
- * (a one-off of the process, near 0 for every later raytracer).  Either handle may be NULL (its fields stay 0). */
-typedef struct { double read_ms, parse_ms, texture_ms, octree_ms, index_ms, upload_ms, hip_init_ms; } rrt_setup_times;
+/* Time of the set-up stages that run once per scene (the reference does all of them inside parse_obj_file_lines, utils.rs:139-213, before its one
+ * frame): model side = file read, .obj/.mtl parse, texture decode; raytracer side = octree build (octree.rs:41-241), own-list index build, upload to
+ * HBM.  With the default GPU set-up octree_ms and index_ms are HIP-event times on the build stream and upload_ms is the rest of
+ * rrt_raytracer_create's wall time (pinned-staging uploads of triangles and textures, allocations, synchronisation); with RRT_FLAG_HOST_SETUP they
+ * are host wall times (octree_ms: the model's host build).  hip_init_ms = bringing the device's HIP context up at the start of
+ * rrt_raytracer_create (a one-off of the process, near 0 for every later raytracer); create_ms = wall time of the whole rrt_raytracer_create;
+ * gpu_setup = 1.0 / 0.0.  Either handle may be NULL (its fields stay 0). */
+typedef struct { double read_ms, parse_ms, texture_ms, octree_ms, index_ms, upload_ms, hip_init_ms, create_ms, gpu_setup; } rrt_setup_times;
 int rrt_get_setup_times(const rrt_model *m, const rrt_raytracer *rt, rrt_setup_times *out);
 int rrt_device_count(int *count);
 const char *rrt_strerror(int status);

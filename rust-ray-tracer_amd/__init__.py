@@ -31,7 +31,9 @@ class RrtError(RuntimeError):
         self.detail = detail
 
 
-FLAG_NO_CULL, FLAG_LANE_FILTER, FLAG_BUNDLE_FILTER, FLAG_RAY_WALK = 1, 2, 4, 8   # RRT_FLAG_*, include/rrt.h
+FLAG_NO_CULL, FLAG_LANE_FILTER, FLAG_BUNDLE_FILTER, FLAG_RAY_WALK, FLAG_HOST_SETUP = 1, 2, 4, 8, 16   # RRT_FLAG_*, include/rrt.h
+BUFFERS = ("nodes", "geom", "attr", "supers", "cboxes", "child_boxes", "tboxes", "suspects", "oct_box", "oct_first_child", "oct_tri_count", "oct_own_off",
+           "oct_own_idx", "slot_tri", "slot_pos")   # RRT_BUF_*
 VARIANT_NAMES = ("lane", "bundle", "ray")   # rrt_stats.filter_variant
 
 # status codes, include/rrt.h
@@ -69,7 +71,7 @@ class CStats(C.Structure):
 
 
 class CSetupTimes(C.Structure):
-    _fields_ = [(n, C.c_double) for n in ("read_ms", "parse_ms", "texture_ms", "octree_ms", "index_ms", "upload_ms", "hip_init_ms")]
+    _fields_ = [(n, C.c_double) for n in ("read_ms", "parse_ms", "texture_ms", "octree_ms", "index_ms", "upload_ms", "hip_init_ms", "create_ms", "gpu_setup")]
 
 
 # every symbol include/rrt.h declares: (restype, argtypes)
@@ -106,6 +108,8 @@ SYMBOLS = {
     "rrt_render_progressive": (C.c_int, [_P, C.c_uint32, C.c_uint32, _u32p, C.c_uint32, _P, _P]),
     "rrt_get_ray_colours": (C.c_int, [_P, C.c_uint32, _dp, _dp, _u32p]),
     "rrt_intersect_rays": (C.c_int, [_P, C.c_uint32, _dp, _dp, _dp, _u8p, _dp, _dp, _dp, _u32p]),
+    "rrt_raytracer_get_octree": (C.c_int, [_P, C.POINTER(CModelInfo), _dp, _u32p, _u32p, _u32p, _u32p]),
+    "rrt_raytracer_get_buffer": (C.c_int, [_P, C.c_uint32, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "rrt_last_stats": (C.c_int, [_P, C.POINTER(CStats)]),
     "rrt_get_setup_times": (C.c_int, [_P, _P, C.POINTER(CSetupTimes)]),
     "rrt_device_count": (C.c_int, [C.POINTER(C.c_int)]),
@@ -194,9 +198,17 @@ class SceneData:
 
     def __init__(self, handle: int):
         self._h = _P(handle)
-        info = CModelInfo()
-        _check(lib().rrt_model_get_info(self._h, C.byref(info)), "rrt_model_get_info")
-        self.info = {n: getattr(info, n) for n, _ in CModelInfo._fields_}
+        self._info = None
+
+    @property
+    def info(self) -> dict:
+        """rrt_model_get_info.  Builds the HOST copy of the octree on first use (the default GPU set-up of a RayTracer never needs it), so this is
+        also where a too-deep tree (RRT_ERR_DEPTH) is reported on the host side."""
+        if self._info is None:
+            info = CModelInfo()
+            _check(lib().rrt_model_get_info(self._h, C.byref(info)), "rrt_model_get_info")
+            self._info = {n: getattr(info, n) for n, _ in CModelInfo._fields_}
+        return self._info
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -278,15 +290,16 @@ class RayTracer:
 
     def __init__(self, scene_data: SceneData, lights: Iterable[Light], origin: Vector3d = DEFAULT_ORIGIN, device: int = 0,
                  surface_offset: float = 0.0001, max_reflection_depth: int = 5, viewport=(1.0, 1.0, 1.0), no_cull: bool = False,
-                 box_filter: Optional[str] = None):
+                 box_filter: Optional[str] = None, host_setup: bool = False):
         """no_cull=True (RRT_FLAG_NO_CULL): walk every own list in full, in list order, as ray.rs:119-129; default uses the cluster boxes.
         box_filter: None = rule of thumb on the first frame of a size, measured on the second, "lane" / "bundle" / "ray" = forced (RRT_FLAG_LANE_FILTER / RRT_FLAG_BUNDLE_FILTER /
-        RRT_FLAG_RAY_WALK); same pixels."""
+        RRT_FLAG_RAY_WALK); same pixels.  host_setup=True (RRT_FLAG_HOST_SETUP): octree, index and records built on the host and uploaded (default: built on
+        the GPU, csrc/scene_build.hip); same bytes in HBM."""
         self.scene_data, self.lights, self.origin, self.device = scene_data, list(lights), origin, device
         cl = (CLight * max(1, len(self.lights)))()
         for i, l in enumerate(self.lights):
             cl[i] = CLight(l.kind, 0, float(l.intensity), l.v._c())
-        flags = (FLAG_NO_CULL if no_cull else 0) | {None: 0, "lane": FLAG_LANE_FILTER, "bundle": FLAG_BUNDLE_FILTER, "ray": FLAG_RAY_WALK}[box_filter]
+        flags = (FLAG_NO_CULL if no_cull else 0) | (FLAG_HOST_SETUP if host_setup else 0) | {None: 0, "lane": FLAG_LANE_FILTER, "bundle": FLAG_BUNDLE_FILTER, "ray": FLAG_RAY_WALK}[box_filter]
         opt = COptions(surface_offset, max_reflection_depth, flags, *map(float, viewport))
         out = _P()
         _check(lib().rrt_raytracer_create(scene_data._h, cl, len(self.lights), origin._c(), C.byref(opt), device, C.byref(out)), "rrt_raytracer_create")
@@ -296,6 +309,27 @@ class RayTracer:
         h, self._h = getattr(self, "_h", None), None
         if h and _lib is not None:
             _lib.rrt_raytracer_destroy(h)
+
+    def octree(self) -> dict:
+        """The octree this raytracer's GPU set-up built (rrt_raytracer_get_octree): same dict as SceneData.octree(), plus "info"."""
+        info = CModelInfo()
+        _check(lib().rrt_raytracer_get_octree(self._h, C.byref(info), None, None, None, None, None), "rrt_raytracer_get_octree")
+        n = info.n_nodes
+        aabb = np.empty((n, 6)); fc = np.empty(n, np.uint32); tc = np.empty(n, np.uint32); off = np.empty(n + 1, np.uint32)
+        idx = np.empty(info.n_tris_in_tree, np.uint32)
+        u = lambda a: a.ctypes.data_as(_u32p)
+        _check(lib().rrt_raytracer_get_octree(self._h, None, _d(aabb), u(fc), u(tc), u(off), u(idx)), "rrt_raytracer_get_octree")
+        return dict(aabb=aabb, first_child=fc, tri_count=tc, own_off=off, own_idx=idx, max_depth=info.max_depth,
+                    info={k: getattr(info, k) for k, _ in CModelInfo._fields_})
+
+    def buffer(self, name: str) -> np.ndarray:
+        """Raw bytes of one scene buffer in HBM (rrt_raytracer_get_buffer; tests compare the GPU set-up with the host set-up)."""
+        which = BUFFERS.index(name)
+        nb = C.c_size_t(0)
+        _check(lib().rrt_raytracer_get_buffer(self._h, which, None, 0, C.byref(nb)), "rrt_raytracer_get_buffer")
+        out = np.empty(nb.value, np.uint8)
+        _check(lib().rrt_raytracer_get_buffer(self._h, which, out.ctypes.data_as(_P), nb.value, None), "rrt_raytracer_get_buffer")
+        return out
 
     # raytracer.rs:29, batched
     def get_ray_colours(self, origins, dirs) -> np.ndarray:

@@ -16,6 +16,7 @@
 #include "device_scene.hpp"
 #include "model.hpp"
 #include "parallel.hpp"
+#include "scene_build.hpp"
 
 struct rrt_model { rrt::Model m; };
 
@@ -37,6 +38,11 @@ struct rrt_raytracer {
     size_t host_fb_bytes = 0;
     uint32_t n_suspects = 0;         // triangles whose plane contains the origin (exactness guard, clusters.cpp)
     double index_ms = 0, upload_ms = 0, hip_init_ms = 0;  // set-up stages of rrt_raytracer_create
+    double octree_ms = 0, create_ms = 0;                  // GPU set-up: octree build on the device; wall time of the whole rrt_raytracer_create
+    bool gpu_setup = false;                               // scene built on the device (default) or on the host (RRT_FLAG_HOST_SETUP)
+    rrt::GpuScene gs{};                                   // GPU set-up: the device-side octree and the sizes of the scene buffers
+    rrt_model_info tree_info{};                           // GPU set-up: what rrt_model_get_info reports, from the device-built tree
+    struct Buf { const void* p = nullptr; size_t bytes = 0; } bufs[16];   // rrt_raytracer_get_buffer
     hipStream_t own_stream = nullptr;   // rrt_render's stream (non-blocking: independent of the legacy default stream)
     void* staging = nullptr;         // pinned host staging for callers whose framebuffer is pageable memory
     size_t staging_bytes = 0;
@@ -78,18 +84,28 @@ template <class F> int guarded(F&& f) {
 // always loaded before a raytracer is created, so the loaders start that work on a helper thread and rrt_raytracer_create finds it done.
 struct DeviceWarmer {
     std::thread th; std::once_flag once; std::mutex mu; bool joined = false;
+    // HIP's current device is per thread, and the device a raytracer will use is only known at rrt_raytracer_create.  The helper warms the device
+    // named by RRT_WARM_DEVICE, else LOCAL_RANK (one process per GPU under torchrun), else device 0 when it is the only one visible; with several
+    // devices visible and no hint it brings up nothing device-specific (it would put a context and an allocation on GPU 0 for every rank).
+    static int hinted_device(int n_dev) {
+        for (const char* name : {"RRT_WARM_DEVICE", "LOCAL_RANK"})
+            if (const char* e = std::getenv(name)) { char* end = nullptr; const long v = std::strtol(e, &end, 10); if (end != e && v >= 0 && v < n_dev) return (int)v; }
+        return n_dev == 1 ? 0 : -1;
+    }
     void start() {
         std::call_once(once, [this] {
             th = std::thread([] {
                 int n = 0;
                 if (hipGetDeviceCount(&n) != hipSuccess || n == 0) { (void)hipGetLastError(); return; }
-                if (hipFree(nullptr) == hipSuccess) {
+                const int dev = hinted_device(n);
+                if (dev >= 0 && hipSetDevice(dev) == hipSuccess && hipFree(nullptr) == hipSuccess) {
                     void* p = nullptr; char probe[256] = {};
                     if (hipMalloc(&p, 1 << 20) == hipSuccess) {           // the first allocation and the first host-to-device copy of a process set up the
                         (void)hipMemcpy(p, probe, sizeof probe, hipMemcpyHostToDevice);   // runtime's memory pools and staging buffers (~80 ms), whoever issues them
                         (void)hipFree(p);
                     }
                     preload_kernels();
+                    staged_upload_warm();                                 // the pinned staging ring of the set-up uploads (scene_build.hip)
                 }
                 (void)hipGetLastError();
             });
@@ -108,7 +124,6 @@ Box default_root(const double* root) {
 }
 
 void validate_model(const Model& m) {
-    if (m.tree.max_depth > RRT_MAX_OCTREE_DEPTH) throw Error{RRT_ERR_DEPTH, "octree depth " + std::to_string(m.tree.max_depth) + " exceeds RRT_MAX_OCTREE_DEPTH"};
     for (auto& t : m.textures) if (t.width == 0 || t.height == 0 || t.rgb.size() != (size_t)3 * t.width * t.height) throw Error{RRT_ERR_INVALID_ARG, "texture with bad dimensions"};
     for (auto& mat : m.materials) {
         if (mat.tex < 0 || (size_t)mat.tex >= m.textures.size()) throw Error{RRT_ERR_INVALID_ARG, "material texture index out of range"};
@@ -312,18 +327,18 @@ int rrt_model_from_arrays(uint32_t n_tris, const double* pos, const double* uv, 
             M.textures[i].width = tex[i].width; M.textures[i].height = tex[i].height;
             M.textures[i].rgb.assign(tex[i].rgb, tex[i].rgb + (size_t)3 * tex[i].width * tex[i].height);
         }
-        M.triangles.resize(n_tris);
-        auto rd = [](const double* p) { Vec3 v; v.x = p[0]; v.y = p[1]; v.z = p[2]; return v; };
-        for (uint32_t i = 0; i < n_tris; i++) {
-            Triangle& t = M.triangles[i];
-            t.v1 = rd(pos + 9 * (size_t)i); t.v2 = rd(pos + 9 * (size_t)i + 3); t.v3 = rd(pos + 9 * (size_t)i + 6);
-            t.t1 = rd(uv + 9 * (size_t)i);  t.t2 = rd(uv + 9 * (size_t)i + 3);  t.t3 = rd(uv + 9 * (size_t)i + 6);
-            t.n1 = rd(nrm + 9 * (size_t)i); t.n2 = rd(nrm + 9 * (size_t)i + 3); t.n3 = rd(nrm + 9 * (size_t)i + 6);
-            t.mat = mat[i];
-        }
-        const auto t0 = std::chrono::steady_clock::now();
-        build_octree(M.triangles, M.root, M.tree);
-        M.octree_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        M.triangles.resize_uninit(n_tris);
+        parallel_ranges(n_tris, 1 << 14, [&](size_t lo, size_t hi, size_t) {
+            auto rd = [](const double* p) { Vec3 v; v.x = p[0]; v.y = p[1]; v.z = p[2]; return v; };
+            for (size_t i = lo; i < hi; i++) {
+                Triangle& t = M.triangles[i];
+                t.v1 = rd(pos + 9 * i); t.v2 = rd(pos + 9 * i + 3); t.v3 = rd(pos + 9 * i + 6);
+                t.t1 = rd(uv + 9 * i);  t.t2 = rd(uv + 9 * i + 3);  t.t3 = rd(uv + 9 * i + 6);
+                t.n1 = rd(nrm + 9 * i); t.n2 = rd(nrm + 9 * i + 3); t.n3 = rd(nrm + 9 * i + 6);
+                t.mat = mat[i]; t._pad = 0;
+            }
+        });
+        // (the octree is built where it is needed: on the GPU in rrt_raytracer_create, or by host_tree() for the getters below)
         validate_model(M);
         *out = m.release();
         return RRT_OK;
@@ -335,7 +350,7 @@ void rrt_model_destroy(rrt_model* m) { delete m; }
 int rrt_model_get_info(const rrt_model* m, rrt_model_info* out) {
     return guarded([&]() -> int {
         if (!m || !out) throw Error{RRT_ERR_INVALID_ARG, "null argument"};
-        const FlatOctree& T = m->m.tree;
+        const FlatOctree& T = host_tree(m->m);
         std::memset(out, 0, sizeof *out);
         out->n_tris = (uint32_t)m->m.triangles.size();
         out->n_tris_in_tree = (uint32_t)T.own_idx.size();
@@ -382,7 +397,7 @@ int rrt_model_get_texture(const rrt_model* m, uint32_t index, rrt_texture* out) 
 int rrt_model_get_octree(const rrt_model* m, double* aabb, uint32_t* first_child, uint32_t* tri_count, uint32_t* own_off, uint32_t* own_idx) {
     return guarded([&]() -> int {
         if (!m) throw Error{RRT_ERR_INVALID_ARG, "null model"};
-        const FlatOctree& T = m->m.tree;
+        const FlatOctree& T = host_tree(m->m);
         const size_t n = T.box.size();
         if (aabb) for (size_t i = 0; i < n; i++) for (int k = 0; k < 3; k++) { aabb[6 * i + k] = T.box[i].lo[k]; aabb[6 * i + 3 + k] = T.box[i].hi[k]; }
         if (first_child) std::copy(T.first_child.begin(), T.first_child.end(), first_child);
@@ -408,6 +423,189 @@ int rrt_decode_image_file(const char* path, uint8_t** rgb, uint32_t* width, uint
 }
 
 // ------------------------------------------------------------------------------------------------ raytracer
+namespace {
+
+// ids of rrt_raytracer_get_buffer (rrt.h: RRT_BUF_*)
+enum { kBufNodes = 0, kBufGeom, kBufAttr, kBufSupers, kBufCboxes, kBufChildBoxes, kBufTboxes, kBufSuspects, kBufOctBox, kBufOctFirstChild, kBufOctTriCount, kBufOctOwnOff, kBufOctOwnIdx, kBufSlotTri, kBufSlotPos, kBufCount };
+
+void upload_materials_and_textures(rrt_raytracer* rt, const Model& M, hipStream_t st, std::vector<DevTexture>& texs, std::vector<DevMaterial>& mats) {
+    texs.resize(M.textures.size());
+    for (size_t i = 0; i < texs.size(); i++) {
+        void* d = nullptr;
+        const size_t bytes = M.textures[i].rgb.size();
+        const size_t padded = (bytes + 255) & ~(size_t)255;
+        if (rt->arena && rt->arena_used + padded <= rt->arena_bytes) { d = static_cast<char*>(rt->arena) + rt->arena_used; rt->arena_used += padded; }
+        else { HIP_TRY(hipMalloc(&d, bytes ? bytes : 1)); rt->allocs.push_back(d); }
+        try { staged_upload(d, M.textures[i].rgb.data(), bytes, st); } catch (const HipBuildFail& f) { throw HipFail{(hipError_t)f.hip_error, f.what}; }
+        rt->scene_bytes += bytes;
+        texs[i].rgb = static_cast<const uint8_t*>(d); texs[i].width = M.textures[i].width; texs[i].height = M.textures[i].height;
+    }
+    mats.resize(M.materials.size());
+    for (size_t i = 0; i < mats.size(); i++) {
+        const rrt_material& s = M.materials[i]; DevMaterial& d = mats[i];
+        d.ka[0] = s.ka.x; d.ka[1] = s.ka.y; d.ka[2] = s.ka.z; d.kd[0] = s.kd.x; d.kd[1] = s.kd.y; d.kd[2] = s.kd.z;
+        d.ks[0] = s.ks.x; d.ks[1] = s.ks.y; d.ks[2] = s.ks.z; d.ns = s.ns; d.kr = s.kr; d.tex = s.tex; d.bump = s.bump;
+        d.tex_desc = texs[s.tex]; d.bump_desc = s.bump >= 0 ? texs[s.bump] : DevTexture{nullptr, 0, 0};
+    }
+}
+
+// ---- set-up on the HOST (round-2 path, RRT_FLAG_HOST_SETUP): octree.cpp + clusters.cpp + the fill loops below, then one upload.  Kept as the
+// second implementation the GPU set-up is checked against byte for byte (tests/test_gpu_build.py), and for A/B timing.
+void setup_on_host(rrt_raytracer* rt, const Model& M, rrt_vec3 origin, const rrt_options& o, uint32_t& max_depth) {
+    using clk = std::chrono::steady_clock;
+    const FlatOctree& T = host_tree(M);
+    rt->octree_ms = M.octree_ms;
+    max_depth = T.max_depth;
+    const size_t n_nodes = T.box.size(), n_slots = T.own_idx.size();   // n_slots: every triangle in the tree appears in exactly one own list
+    const auto t_index0 = clk::now();
+    ClusterSet CS;
+    build_clusters(M, !(o.flags & RRT_FLAG_NO_CULL), CS);
+    const size_t n_slots_c = CS.slot_tri.size();
+    // (plain arrays: a std::vector would zero 250 MB on one thread before the workers fill it)
+    std::unique_ptr<DevNode[]> nodes(new DevNode[n_nodes ? n_nodes : 1]);
+    parallel_ranges(n_nodes, 1 << 14, [&](size_t nb, size_t ne, size_t) {
+    for (size_t i = nb; i < ne; i++) {
+        DevNode& d = nodes[i];
+        for (int k = 0; k < 3; k++) {
+            d.lo[k] = T.box[i].lo[k]; d.hi[k] = T.box[i].hi[k];
+            // the split plane: child TFR (index 6, octree.rs:216-225) has lo == mid on every axis; for a leaf recompute it as subdivide would
+            d.mid[k] = T.first_child[i] ? T.box[T.first_child[i] + 6].lo[k] : d.lo[k] + (d.hi[k] - d.lo[k]) / 2.0;
+        }
+        d.first_child = T.first_child[i]; d.sup_begin = CS.node_sup_begin[i]; d.sup_count = CS.node_sup_count[i];
+        d.s0_begin = d.sup_count ? CS.supers[d.sup_begin].tri_begin : 0;
+        d.flags = (T.tri_count[i] ? 0x100u : 0u) | ((d.sup_count ? CS.supers[d.sup_begin].tri_count : 0u) << 24);
+        d.leaf_base = CS.node_leaf_slot[i] != kPadSlot ? CS.node_leaf_slot[i] : 0;   // a leaf has no children: the field holds its own dense slot instead
+        if (d.first_child) for (uint32_t k = 8; k-- > 0;) {
+            if (T.tri_count[d.first_child + k]) d.flags |= 1u << k;
+            if (CS.node_leaf_slot[d.first_child + k] != kPadSlot) { d.flags |= 1u << (9 + k); d.leaf_base = CS.node_leaf_slot[d.first_child + k]; }   // ends at the first one
+        }
+    }
+    });
+    std::unique_ptr<DevTriGeom[]> geom(new DevTriGeom[n_slots_c ? n_slots_c : 1]); std::unique_ptr<DevTriAttr[]> attr(new DevTriAttr[n_slots_c ? n_slots_c : 1]);
+    parallel_ranges(n_slots_c, 1 << 14, [&](size_t sb, size_t se, size_t) {
+    for (size_t s = sb; s < se; s++) {
+        if (CS.slot_tri[s] == kPadSlot) { std::memset(&geom[s], 0, sizeof(DevTriGeom)); std::memset(&attr[s], 0, sizeof(DevTriAttr)); attr[s].orig = kPadSlot; continue; }
+        const Triangle& t = M.triangles[CS.slot_tri[s]];
+        DevTriGeom& g = geom[s];
+        g.v1[0] = t.v1.x; g.v1[1] = t.v1.y; g.v1[2] = t.v1.z;
+        g.e1[0] = t.v2.x - t.v1.x; g.e1[1] = t.v2.y - t.v1.y; g.e1[2] = t.v2.z - t.v1.z;   // ray.rs:60
+        g.e2[0] = t.v3.x - t.v1.x; g.e2[1] = t.v3.y - t.v1.y; g.e2[2] = t.v3.z - t.v1.z;   // ray.rs:61
+        g.pos = CS.slot_pos[s]; g._pad = 0;
+        DevTriAttr& a = attr[s];
+        a.uv[0] = t.t1.x; a.uv[1] = t.t1.y; a.uv[2] = t.t2.x; a.uv[3] = t.t2.y; a.uv[4] = t.t3.x; a.uv[5] = t.t3.y;
+        a.nrm[0] = t.n1.x; a.nrm[1] = t.n1.y; a.nrm[2] = t.n1.z; a.nrm[3] = t.n2.x; a.nrm[4] = t.n2.y; a.nrm[5] = t.n2.z;
+        a.nrm[6] = t.n3.x; a.nrm[7] = t.n3.y; a.nrm[8] = t.n3.z;
+        a.mat = t.mat; a.orig = CS.slot_tri[s];
+    }
+    });
+    const auto t_index1 = clk::now();
+    {
+        size_t need = (size_t)1 << 20;
+        for (auto& t : M.textures) need += t.rgb.size() + 256;
+        need += n_nodes * sizeof(DevNode) + n_slots_c * (sizeof(DevTriGeom) + sizeof(DevTriAttr)) + 4096;
+        need += (CS.supers.size() + CS.cboxes.size() + CS.child_boxes.size() + CS.tboxes.size()) * 32 + 4096;
+        need += M.materials.size() * sizeof(DevMaterial) + M.textures.size() * sizeof(DevTexture) + (RRT_MAX_SUSPECTS + 1) * sizeof(DevSuspect);
+        HIP_TRY(hipMalloc(&rt->arena, need));
+        rt->allocs.push_back(rt->arena);
+        rt->arena_bytes = need;
+    }
+    std::vector<DevTexture> texs; std::vector<DevMaterial> mats;
+    upload_materials_and_textures(rt, M, nullptr, texs, mats);
+    DevScene& S = rt->scene;
+    auto keep = [&](int id, const void* p, size_t bytes) { rt->bufs[id].p = p; rt->bufs[id].bytes = bytes; };
+    S.nodes = upload(rt, nodes.get(), n_nodes);                              keep(kBufNodes, S.nodes, n_nodes * sizeof(DevNode));
+    S.geom = upload(rt, geom.get(), n_slots_c);                              keep(kBufGeom, S.geom, n_slots_c * sizeof(DevTriGeom));
+    S.supers = upload(rt, CS.supers.data(), CS.supers.size());               keep(kBufSupers, S.supers, CS.supers.size() * sizeof(DevSuper));
+    S.cboxes = upload(rt, CS.cboxes.data(), CS.cboxes.size());               keep(kBufCboxes, S.cboxes, CS.cboxes.size() * sizeof(DevClusterBox));
+    S.child_boxes = upload(rt, CS.child_boxes.data(), CS.child_boxes.size()); keep(kBufChildBoxes, S.child_boxes, CS.child_boxes.size() * sizeof(DevClusterBox));
+    S.tboxes = upload(rt, CS.tboxes.data(), CS.tboxes.size());               keep(kBufTboxes, S.tboxes, CS.tboxes.size() * sizeof(DevClusterBox));
+    S.has_groups = CS.has_groups ? 1u : 0u;
+    S.bounds_plain = 1u;
+    for (size_t i = 0; i < n_nodes; i++) { const DevNode& d = nodes[i];
+        for (int k = 0; k < 3; k++)
+            for (double v : {d.lo[k], d.mid[k], d.hi[k]})
+                if (!(v == 0.0 || (std::fabs(v) > 0x1p-200 && std::fabs(v) < 0x1p200))) S.bounds_plain = 0u;
+    }
+    S.cull_limit = (float)(CS.scene_magnitude * 4.0);
+    std::vector<DevSuspect> sus;                                      // (lives until the hipDeviceSynchronize below: uploads are asynchronous)
+    {   // exactness guard of the index for rays from `origin` (clusters.cpp, find_origin_suspects)
+        const double org[3] = {origin.x, origin.y, origin.z};
+        if (!(o.flags & RRT_FLAG_NO_CULL)) find_origin_suspects(M, org, CS.pad, sus);
+        rt->n_suspects = (uint32_t)sus.size();
+        if (sus.size() > RRT_MAX_SUSPECTS) sus.resize(1);              // beyond the cap every ray from the origin runs unfiltered; the list is not read
+        S.suspects = upload(rt, sus.data(), sus.size());               keep(kBufSuspects, S.suspects, sus.size() * sizeof(DevSuspect));
+    }
+    S.attr = upload(rt, attr.get(), n_slots_c);                              keep(kBufAttr, S.attr, n_slots_c * sizeof(DevTriAttr));
+    S.mats = upload(rt, mats.data(), mats.size());
+    S.tex = upload(rt, texs.data(), texs.size());
+    S.n_nodes = (uint32_t)n_nodes; S.n_slots = (uint32_t)n_slots; S.n_mats = (uint32_t)mats.size(); S.n_tex = (uint32_t)texs.size();
+    S.fc_mask = CS.inline_leaves ? 0x00FFFFFFu : 0xFFFFFFFFu;
+    HIP_TRY(hipDeviceSynchronize());
+    rt->index_ms = std::chrono::duration<double, std::milli>(t_index1 - t_index0).count();
+    rt->upload_ms = std::chrono::duration<double, std::milli>(clk::now() - t_index1).count();
+}
+
+// ---- set-up on the GPU (default): the triangle array goes up through pinned staging, then octree, index and records are built there
+// (scene_build.hip).  Nothing of the tree ever exists on the host unless a getter asks for it.
+void setup_on_gpu(rrt_raytracer* rt, const Model& M, rrt_vec3 origin, const rrt_options& o, uint32_t& max_depth) {
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
+    hipStream_t st = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sg{st};
+    {   // textures + small tables: one allocation
+        size_t need = (size_t)1 << 16;
+        for (auto& t : M.textures) need += t.rgb.size() + 256;
+        need += M.materials.size() * sizeof(DevMaterial) + M.textures.size() * sizeof(DevTexture) + 1024;
+        HIP_TRY(hipMalloc(&rt->arena, need));
+        rt->allocs.push_back(rt->arena);
+        rt->arena_bytes = need;
+    }
+    std::vector<DevTexture> texs; std::vector<DevMaterial> mats;
+    GpuScene& G = rt->gs;
+    const double org[3] = {origin.x, origin.y, origin.z};
+    try { gpu_build_scene(M.triangles.data(), (uint32_t)M.triangles.size(), M.root, !(o.flags & RRT_FLAG_NO_CULL), org, st, G); }
+    catch (const HipBuildFail& f) { if (G.scene_alloc) { (void)hipFree(G.scene_alloc); G.scene_alloc = nullptr; } throw HipFail{(hipError_t)f.hip_error, f.what}; }
+    catch (...) { if (G.scene_alloc) { (void)hipFree(G.scene_alloc); G.scene_alloc = nullptr; } throw; }
+    rt->allocs.push_back(G.scene_alloc);
+    upload_materials_and_textures(rt, M, st, texs, mats);
+    max_depth = G.max_depth;
+    DevScene& S = rt->scene;
+    S.nodes = G.nodes; S.geom = G.geom; S.attr = G.attr; S.supers = G.supers; S.cboxes = G.cboxes; S.child_boxes = G.child_boxes; S.tboxes = G.tboxes; S.suspects = G.suspects;
+    auto keep = [&](int id, const void* p, size_t bytes) { rt->bufs[id].p = p; rt->bufs[id].bytes = bytes; };
+    keep(kBufNodes, G.nodes, (size_t)G.n_nodes * sizeof(DevNode)); keep(kBufGeom, G.geom, (size_t)G.n_slots_total * sizeof(DevTriGeom)); keep(kBufAttr, G.attr, (size_t)G.n_slots_total * sizeof(DevTriAttr));
+    keep(kBufSupers, G.supers, (size_t)G.n_sup_records * sizeof(DevSuper)); keep(kBufCboxes, G.cboxes, ((size_t)G.n_clusters + 8) * sizeof(DevClusterBox));
+    keep(kBufChildBoxes, G.child_boxes, ((size_t)(G.n_nodes > 1 ? G.n_nodes - 1 : 0) + 8) * sizeof(DevClusterBox)); keep(kBufTboxes, G.tboxes, ((size_t)G.n_list_slots + 8) * sizeof(DevClusterBox));
+    keep(kBufSuspects, G.suspects, (size_t)(G.n_suspects > RRT_MAX_SUSPECTS ? 0 : G.n_suspects) * sizeof(DevSuspect));
+    keep(kBufOctBox, G.oct_box, (size_t)G.n_nodes * 48); keep(kBufOctFirstChild, G.oct_first_child, (size_t)G.n_nodes * 4); keep(kBufOctTriCount, G.oct_tri_count, (size_t)G.n_nodes * 4);
+    keep(kBufOctOwnOff, G.oct_own_off, ((size_t)G.n_nodes + 1) * 4); keep(kBufOctOwnIdx, G.oct_own_idx, (size_t)G.n_in_tree * 4);
+    keep(kBufSlotTri, G.slot_tri, (size_t)G.n_slots_total * 4); keep(kBufSlotPos, G.slot_pos, (size_t)G.n_slots_total * 4);
+    rt->scene_bytes += (size_t)G.n_nodes * sizeof(DevNode) + (size_t)G.n_slots_total * (sizeof(DevTriGeom) + sizeof(DevTriAttr))
+                     + ((size_t)G.n_sup_records + G.n_clusters + 8 + (G.n_nodes > 1 ? G.n_nodes - 1 : 0) + 8 + G.n_list_slots + 8) * 32;
+    S.has_groups = G.has_groups; S.bounds_plain = G.bounds_plain;
+    S.cull_limit = (float)(G.scene_magnitude * 4.0);
+    rt->n_suspects = G.n_suspects;
+    // small tables go through the same stream
+    {
+        void* d_m = static_cast<char*>(rt->arena) + rt->arena_used; rt->arena_used += (mats.size() * sizeof(DevMaterial) + 255) & ~(size_t)255;
+        void* d_t = static_cast<char*>(rt->arena) + rt->arena_used; rt->arena_used += (texs.size() * sizeof(DevTexture) + 255) & ~(size_t)255;
+        if (rt->arena_used > rt->arena_bytes) throw Error{RRT_ERR_OOM, "internal: table arena too small"};
+        if (!mats.empty()) HIP_TRY(hipMemcpyAsync(d_m, mats.data(), mats.size() * sizeof(DevMaterial), hipMemcpyHostToDevice, st));
+        if (!texs.empty()) HIP_TRY(hipMemcpyAsync(d_t, texs.data(), texs.size() * sizeof(DevTexture), hipMemcpyHostToDevice, st));
+        S.mats = static_cast<const DevMaterial*>(d_m); S.tex = static_cast<const DevTexture*>(d_t);
+    }
+    S.n_nodes = G.n_nodes; S.n_slots = G.n_in_tree; S.n_mats = (uint32_t)mats.size(); S.n_tex = (uint32_t)texs.size();
+    S.fc_mask = G.inline_leaves ? 0x00FFFFFFu : 0xFFFFFFFFu;
+    HIP_TRY(hipStreamSynchronize(st));
+    rt->octree_ms = G.ms_octree; rt->index_ms = G.ms_index;
+    rt->upload_ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count() - G.ms_octree - G.ms_index;   // uploads, allocations, synchronisation
+    rrt_model_info& I = rt->tree_info;
+    I.n_tris = (uint32_t)M.triangles.size(); I.n_tris_in_tree = G.n_in_tree; I.n_nodes = G.n_nodes; I.max_depth = G.max_depth;
+    I.n_mats = (uint32_t)M.materials.size(); I.n_tex = (uint32_t)M.textures.size(); I.max_own_count = 0; I.root_own_count = 0;
+}
+
+}  // namespace
+
 int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n_lights, rrt_vec3 origin,
                          const rrt_options* opt, int device, rrt_raytracer** out) {
     return guarded([&]() -> int {
@@ -417,6 +615,7 @@ int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n
         rrt_options o;
         if (opt) o = *opt; else { o.surface_offset = 0.0001; o.max_reflection_depth = 5; o.flags = 0; o.vp_w = o.vp_h = o.vp_d = 1.0; }
         if (o.max_reflection_depth > RRT_MAX_REFLECT) throw Error{RRT_ERR_INVALID_ARG, "max_reflection_depth > 8"};
+        const auto t_create0 = std::chrono::steady_clock::now();
         g_warmer.join();
         int n_dev = 0;
         if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) { (void)hipGetLastError(); throw Error{RRT_ERR_NO_DEVICE, "no HIP device visible"}; }
@@ -429,110 +628,16 @@ int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n
         std::unique_ptr<rrt_raytracer, void (*)(rrt_raytracer*)> rt(new rrt_raytracer, rrt_raytracer_destroy);
         rt->hip_init_ms = hip_init_ms;
         rt->device = device; rt->opt = o;
-        const Model& M = m->m; const FlatOctree& T = M.tree;
-        const size_t n_nodes = T.box.size(), n_slots = T.own_idx.size();   // n_slots: every triangle in the tree appears in exactly one own list
+        const Model& M = m->m;
+        rt->gpu_setup = !(o.flags & RRT_FLAG_HOST_SETUP);
+        uint32_t max_depth = 1;
+        if (rt->gpu_setup) setup_on_gpu(rt.get(), M, origin, o, max_depth); else setup_on_host(rt.get(), M, origin, o, max_depth);
 
-        using clk = std::chrono::steady_clock;
-        const auto t_index0 = clk::now();
-        ClusterSet CS;
-        build_clusters(M, !(o.flags & RRT_FLAG_NO_CULL), CS);
-        const size_t n_slots_c = CS.slot_tri.size();
-        // (plain arrays: a std::vector would zero 250 MB on one thread before the workers fill it)
-        std::unique_ptr<DevNode[]> nodes(new DevNode[n_nodes ? n_nodes : 1]);
-        parallel_ranges(n_nodes, 1 << 14, [&](size_t nb, size_t ne, size_t) {
-        for (size_t i = nb; i < ne; i++) {
-            DevNode& d = nodes[i];
-            for (int k = 0; k < 3; k++) {
-                d.lo[k] = T.box[i].lo[k]; d.hi[k] = T.box[i].hi[k];
-                // the split plane: child TFR (index 6, octree.rs:216-225) has lo == mid on every axis; for a leaf recompute it as subdivide would
-                d.mid[k] = T.first_child[i] ? T.box[T.first_child[i] + 6].lo[k] : d.lo[k] + (d.hi[k] - d.lo[k]) / 2.0;
-            }
-            d.first_child = T.first_child[i]; d.sup_begin = CS.node_sup_begin[i]; d.sup_count = CS.node_sup_count[i];
-            d.s0_begin = d.sup_count ? CS.supers[d.sup_begin].tri_begin : 0;
-            d.flags = (T.tri_count[i] ? 0x100u : 0u) | ((d.sup_count ? CS.supers[d.sup_begin].tri_count : 0u) << 24);
-            d.leaf_base = CS.node_leaf_slot[i] != kPadSlot ? CS.node_leaf_slot[i] : 0;   // a leaf has no children: the field holds its own dense slot instead
-            if (d.first_child) for (uint32_t k = 8; k-- > 0;) {
-                if (T.tri_count[d.first_child + k]) d.flags |= 1u << k;
-                if (CS.node_leaf_slot[d.first_child + k] != kPadSlot) { d.flags |= 1u << (9 + k); d.leaf_base = CS.node_leaf_slot[d.first_child + k]; }   // ends at the first one
-            }
-        }
-        });
-        std::unique_ptr<DevTriGeom[]> geom(new DevTriGeom[n_slots_c ? n_slots_c : 1]); std::unique_ptr<DevTriAttr[]> attr(new DevTriAttr[n_slots_c ? n_slots_c : 1]);
-        parallel_ranges(n_slots_c, 1 << 14, [&](size_t sb, size_t se, size_t) {
-        for (size_t s = sb; s < se; s++) {
-            if (CS.slot_tri[s] == kPadSlot) { std::memset(&geom[s], 0, sizeof(DevTriGeom)); std::memset(&attr[s], 0, sizeof(DevTriAttr)); attr[s].orig = kPadSlot; continue; }
-            const Triangle& t = M.triangles[CS.slot_tri[s]];
-            DevTriGeom& g = geom[s];
-            g.v1[0] = t.v1.x; g.v1[1] = t.v1.y; g.v1[2] = t.v1.z;
-            g.e1[0] = t.v2.x - t.v1.x; g.e1[1] = t.v2.y - t.v1.y; g.e1[2] = t.v2.z - t.v1.z;   // ray.rs:60
-            g.e2[0] = t.v3.x - t.v1.x; g.e2[1] = t.v3.y - t.v1.y; g.e2[2] = t.v3.z - t.v1.z;   // ray.rs:61
-            g.pos = CS.slot_pos[s]; g._pad = 0;
-            DevTriAttr& a = attr[s];
-            a.uv[0] = t.t1.x; a.uv[1] = t.t1.y; a.uv[2] = t.t2.x; a.uv[3] = t.t2.y; a.uv[4] = t.t3.x; a.uv[5] = t.t3.y;
-            a.nrm[0] = t.n1.x; a.nrm[1] = t.n1.y; a.nrm[2] = t.n1.z; a.nrm[3] = t.n2.x; a.nrm[4] = t.n2.y; a.nrm[5] = t.n2.z;
-            a.nrm[6] = t.n3.x; a.nrm[7] = t.n3.y; a.nrm[8] = t.n3.z;
-            a.mat = t.mat; a.orig = CS.slot_tri[s];
-        }
-        });
-        const auto t_index1 = clk::now();
-        {
-            size_t need = (size_t)1 << 20;
-            for (auto& t : M.textures) need += t.rgb.size() + 256;
-            need += n_nodes * sizeof(DevNode) + n_slots_c * (sizeof(DevTriGeom) + sizeof(DevTriAttr)) + 4096;
-            need += (CS.supers.size() + CS.cboxes.size() + CS.child_boxes.size() + CS.tboxes.size()) * 32 + 4096;
-            need += M.materials.size() * sizeof(DevMaterial) + M.textures.size() * sizeof(DevTexture) + (RRT_MAX_SUSPECTS + 1) * sizeof(DevSuspect);
-            HIP_TRY(hipMalloc(&rt->arena, need));
-            rt->allocs.push_back(rt->arena);
-            rt->arena_bytes = need;
-        }
-        const bool trace = std::getenv("RRT_SETUP_TRACE") != nullptr;
-        auto lap = [&, last = t_index1](const char* what) mutable { if (trace) { const auto n = clk::now(); fprintf(stderr, "[setup] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(n - last).count()); last = n; } };
-        lap("arena hipMalloc");
-        std::vector<DevTexture> texs(M.textures.size());
-        for (size_t i = 0; i < texs.size(); i++) {
-            texs[i].rgb = upload(rt.get(), M.textures[i].rgb.data(), M.textures[i].rgb.size());
-            texs[i].width = M.textures[i].width; texs[i].height = M.textures[i].height;
-        }
-        std::vector<DevMaterial> mats(M.materials.size());
-        for (size_t i = 0; i < mats.size(); i++) {
-            const rrt_material& s = M.materials[i]; DevMaterial& d = mats[i];
-            d.ka[0] = s.ka.x; d.ka[1] = s.ka.y; d.ka[2] = s.ka.z; d.kd[0] = s.kd.x; d.kd[1] = s.kd.y; d.kd[2] = s.kd.z;
-            d.ks[0] = s.ks.x; d.ks[1] = s.ks.y; d.ks[2] = s.ks.z; d.ns = s.ns; d.kr = s.kr; d.tex = s.tex; d.bump = s.bump;
-            d.tex_desc = texs[s.tex]; d.bump_desc = s.bump >= 0 ? texs[s.bump] : DevTexture{nullptr, 0, 0};
-        }
-        lap("textures enqueued");
         DevScene& S = rt->scene;
-        S.nodes = upload(rt.get(), nodes.get(), n_nodes);
-        S.geom = upload(rt.get(), geom.get(), n_slots_c);
-        S.supers = upload(rt.get(), CS.supers.data(), CS.supers.size());
-        S.cboxes = upload(rt.get(), CS.cboxes.data(), CS.cboxes.size());
-        S.child_boxes = upload(rt.get(), CS.child_boxes.data(), CS.child_boxes.size());
-        S.tboxes = upload(rt.get(), CS.tboxes.data(), CS.tboxes.size());
         S.cull_enabled = (o.flags & RRT_FLAG_NO_CULL) ? 0u : 1u;
-        S.has_groups = CS.has_groups ? 1u : 0u;
-        S.bounds_plain = 1u;
-        for (size_t i = 0; i < n_nodes; i++) { const DevNode& d = nodes[i];
-            for (int k = 0; k < 3; k++)
-                for (double v : {d.lo[k], d.mid[k], d.hi[k]})
-                    if (!(v == 0.0 || (std::fabs(v) > 0x1p-200 && std::fabs(v) < 0x1p200))) S.bounds_plain = 0u;
-        }
-        S.cull_limit = (float)(CS.scene_magnitude * 4.0);
         S.cull_half_over_limit = S.cull_limit > 0.0f ? 0.5f / S.cull_limit : 0.0f;
-        lap("geometry + index enqueued");
-        std::vector<DevSuspect> sus;                                      // (lives until the hipDeviceSynchronize below: uploads are asynchronous)
-        {   // exactness guard of the index for rays from `origin` (clusters.cpp, find_origin_suspects)
-            const double org[3] = {origin.x, origin.y, origin.z};
-            if (S.cull_enabled) find_origin_suspects(M, org, CS.pad, sus);
-            rt->n_suspects = (uint32_t)sus.size();
-            S.n_suspects = (uint32_t)sus.size();
-            if (sus.size() > RRT_MAX_SUSPECTS) sus.resize(1);              // beyond the cap every ray from the origin runs unfiltered; the list is not read
-            S.suspects = upload(rt.get(), sus.data(), sus.size());
-        }
-        S.attr = upload(rt.get(), attr.get(), n_slots_c);
-        S.mats = upload(rt.get(), mats.data(), mats.size());
-        S.tex = upload(rt.get(), texs.data(), texs.size());
-        S.n_nodes = (uint32_t)n_nodes; S.n_slots = (uint32_t)n_slots; S.n_mats = (uint32_t)mats.size(); S.n_tex = (uint32_t)texs.size();
-        S.n_lights = n_lights; S.max_reflection_depth = o.max_reflection_depth; S.stack_levels = T.max_depth > 1 ? T.max_depth - 1 : 1; S.fc_mask = CS.inline_leaves ? 0x00FFFFFFu : 0xFFFFFFFFu;   // (stack_levels: only internal nodes push a frame; the deepest level holds leaves)
+        S.n_suspects = rt->n_suspects;
+        S.n_lights = n_lights; S.max_reflection_depth = o.max_reflection_depth; S.stack_levels = max_depth > 1 ? max_depth - 1 : 1;   // (stack_levels: only internal nodes push a frame; the deepest level holds leaves)
         S.origin[0] = origin.x; S.origin[1] = origin.y; S.origin[2] = origin.z;
         S.surface_offset = o.surface_offset;
         for (uint32_t i = 0; i < n_lights; i++) {
@@ -543,17 +648,51 @@ int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n
         { void* pb = nullptr; HIP_TRY(hipMalloc(&pb, 24 * sizeof(unsigned long long))); HIP_TRY(hipMemset(pb, 0, 24 * sizeof(unsigned long long)));
           rt->allocs.push_back(pb); S.prof = static_cast<unsigned long long*>(pb); }
 #endif
-        lap("suspects, attr, materials");
         HIP_TRY(hipEventCreate(&rt->ev0)); HIP_TRY(hipEventCreate(&rt->ev1));
-        lap("hipEventCreate x2");
-        HIP_TRY(hipDeviceSynchronize());
-        lap("hipDeviceSynchronize");
-        rt->index_ms = std::chrono::duration<double, std::milli>(t_index1 - t_index0).count();
-        rt->upload_ms = std::chrono::duration<double, std::milli>(clk::now() - t_index1).count();
-        // Own-list filter variant: forced by a flag, else measured on the first frame of each frame size (tune_variant below)
+        // Own-list filter variant: forced by a flag, else a rule of thumb on the first frame of each frame size and measured on the second (tune_variant)
         rt->variant_forced = (o.flags & (RRT_FLAG_BUNDLE_FILTER | RRT_FLAG_LANE_FILTER | RRT_FLAG_RAY_WALK | RRT_FLAG_NO_CULL)) != 0;
         rt->walk = (o.flags & RRT_FLAG_NO_CULL) ? 0 : (o.flags & RRT_FLAG_BUNDLE_FILTER) ? 1 : (o.flags & RRT_FLAG_RAY_WALK) ? 2 : 0;
+        rt->create_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create0).count();
         *out = rt.release();
+        return RRT_OK;
+    });
+}
+
+// The octree as the GPU set-up built it (scene_build.hip), in the reference's node numbering: same layout as rrt_model_get_octree.
+int rrt_raytracer_get_octree(const rrt_raytracer* rt, rrt_model_info* info, double* aabb, uint32_t* first_child, uint32_t* tri_count, uint32_t* own_off, uint32_t* own_idx) {
+    return guarded([&]() -> int {
+        if (!rt) throw Error{RRT_ERR_INVALID_ARG, "null raytracer"};
+        if (!rt->gpu_setup) throw Error{RRT_ERR_UNSUPPORTED, "this raytracer was set up on the host (RRT_FLAG_HOST_SETUP): ask the model (rrt_model_get_octree)"};
+        DeviceGuard guard(rt->device);
+        const GpuScene& G = rt->gs;
+        if (aabb) HIP_TRY(hipMemcpy(aabb, G.oct_box, (size_t)G.n_nodes * 48, hipMemcpyDeviceToHost));
+        if (first_child) HIP_TRY(hipMemcpy(first_child, G.oct_first_child, (size_t)G.n_nodes * 4, hipMemcpyDeviceToHost));
+        if (tri_count) HIP_TRY(hipMemcpy(tri_count, G.oct_tri_count, (size_t)G.n_nodes * 4, hipMemcpyDeviceToHost));
+        if (own_off) HIP_TRY(hipMemcpy(own_off, G.oct_own_off, ((size_t)G.n_nodes + 1) * 4, hipMemcpyDeviceToHost));
+        if (own_idx && G.n_in_tree) HIP_TRY(hipMemcpy(own_idx, G.oct_own_idx, (size_t)G.n_in_tree * 4, hipMemcpyDeviceToHost));
+        if (info) {
+            *info = rt->tree_info;
+            std::vector<uint32_t> off((size_t)G.n_nodes + 1);
+            HIP_TRY(hipMemcpy(off.data(), G.oct_own_off, off.size() * 4, hipMemcpyDeviceToHost));
+            info->root_own_count = off[1] - off[0];
+            for (size_t i = 0; i + 1 < off.size(); i++) info->max_own_count = std::max(info->max_own_count, off[i + 1] - off[i]);
+        }
+        return RRT_OK;
+    });
+}
+
+// Developer / test introspection: the bytes of one of the scene buffers in HBM (RRT_BUF_*).  out may be NULL to ask for the size only.
+int rrt_raytracer_get_buffer(const rrt_raytracer* rt, uint32_t which, void* out, size_t capacity, size_t* bytes) {
+    return guarded([&]() -> int {
+        if (!rt || which >= (uint32_t)kBufCount) throw Error{RRT_ERR_INVALID_ARG, "bad buffer id"};
+        const auto& b = rt->bufs[which];
+        if (!b.p && b.bytes) throw Error{RRT_ERR_UNSUPPORTED, "buffer not kept by this set-up path"};
+        if (bytes) *bytes = b.bytes;
+        if (out) {
+            if (capacity < b.bytes) throw Error{RRT_ERR_INVALID_ARG, "buffer too small"};
+            DeviceGuard guard(rt->device);
+            if (b.bytes) HIP_TRY(hipMemcpy(out, b.p, b.bytes, hipMemcpyDeviceToHost));
+        }
         return RRT_OK;
     });
 }
@@ -1081,7 +1220,11 @@ int rrt_get_setup_times(const rrt_model* m, const rrt_raytracer* rt, rrt_setup_t
         if (!out) throw Error{RRT_ERR_INVALID_ARG, "null argument"};
         std::memset(out, 0, sizeof *out);
         if (m) { out->read_ms = m->m.read_ms; out->parse_ms = m->m.parse_ms; out->texture_ms = m->m.texture_ms; out->octree_ms = m->m.octree_ms; }
-        if (rt) { out->index_ms = rt->index_ms; out->upload_ms = rt->upload_ms; out->hip_init_ms = rt->hip_init_ms; }
+        if (rt) {
+            out->index_ms = rt->index_ms; out->upload_ms = rt->upload_ms; out->hip_init_ms = rt->hip_init_ms; out->create_ms = rt->create_ms;
+            out->gpu_setup = rt->gpu_setup ? 1.0 : 0.0;
+            if (rt->gpu_setup || !m) out->octree_ms = rt->octree_ms;       // the tree this raytracer traces was built on its device
+        }
         return RRT_OK;
     });
 }

@@ -34,6 +34,7 @@ TriBox tri_box(const Triangle& t) {
         b.lo[k] = std::min(x[k][0], std::min(x[k][1], x[k][2]));
         b.hi[k] = std::max(x[k][0], std::max(x[k][1], x[k][2]));
         b.c[k] = (b.lo[k] + b.hi[k]) * 0.5;
+        if (b.c[k] != b.c[k]) b.c[k] = 0.0;   // NaN coordinates: keep (centroid, position) a strict total order (the splits below rank by it)
     }
     return b;
 }
@@ -89,7 +90,7 @@ struct RangeOut {
 
 void index_node(const Model& m, size_t node, bool enable_cull, double pad, RangeOut& R, uint32_t& sup_begin, uint32_t& sup_count, double own_lo[3], double own_hi[3],
                 std::vector<TriBox>& boxes, std::vector<uint32_t>& items) {
-    const FlatOctree& T = m.tree;
+    const FlatOctree& T = host_tree(m);
     const uint32_t b = T.own_off[node], e = T.own_off[node + 1];
     sup_begin = (uint32_t)R.supers.size(); sup_count = 0;
     for (int k = 0; k < 3; k++) { own_lo[k] = DBL_MAX; own_hi[k] = -DBL_MAX; }
@@ -174,7 +175,7 @@ void index_node(const Model& m, size_t node, bool enable_cull, double pad, Range
 }  // namespace
 
 void build_clusters(const Model& m, bool enable_cull, ClusterSet& out) {
-    const FlatOctree& T = m.tree;
+    const FlatOctree& T = host_tree(m);
     const size_t n_nodes = T.box.size();
     out = ClusterSet{};
     out.node_sup_begin.assign(n_nodes, 0); out.node_sup_count.assign(n_nodes, 0);
@@ -276,7 +277,7 @@ void find_origin_suspects(const Model& m, const double origin[3], double pad, st
     out.clear();
     if (!(pad > 0)) return;
     const double eps = 0x1p-53;
-    const std::vector<uint32_t>& idx = m.tree.own_idx;
+    const std::vector<uint32_t>& idx = host_tree(m).own_idx;
     std::vector<std::vector<DevSuspect>> found(host_threads());
     parallel_ranges(idx.size(), 1 << 15, [&](size_t ib, size_t ie, size_t part) {
     std::vector<DevSuspect>& out = found[part];

@@ -2,6 +2,9 @@
 // Plain f64 everywhere, as the reference (src/scene/engine.rs:9-14).
 #pragma once
 #include <cstdint>
+#include <cstdlib>
+#include <mutex>
+#include <new>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -18,6 +21,27 @@ struct Triangle {
     Vec3 t1, t2, t3;   // only .x/.y are read (raytracer.rs:45-50)
     Vec3 n1, n2, n3;
     uint32_t mat = 0;
+    uint32_t _pad = 0;
+};
+static_assert(sizeof(Triangle) == 224, "Triangle: 27 doubles + material index + padding (uploaded as is, scene_build.hip)");
+
+// SceneData.triangles.  A plain array whose resize() does NOT initialise: at a million triangles a value-initialising std::vector::resize is a
+// 224 MB single-threaded memset before the (parallel) writers even start.  Every writer assigns every field of every element.
+class TriArray {
+    Triangle* p_ = nullptr; size_t n_ = 0;
+public:
+    TriArray() = default;
+    TriArray(const TriArray&) = delete; TriArray& operator=(const TriArray&) = delete;
+    ~TriArray() { std::free(p_); }
+    void resize_uninit(size_t n) {
+        std::free(p_); p_ = nullptr; n_ = 0;
+        if (n) { p_ = static_cast<Triangle*>(std::malloc(n * sizeof(Triangle))); if (!p_) throw std::bad_alloc(); }
+        n_ = n;
+    }
+    size_t size() const { return n_; }
+    Triangle* data() { return p_; } const Triangle* data() const { return p_; }
+    Triangle& operator[](size_t i) { return p_[i]; } const Triangle& operator[](size_t i) const { return p_[i]; }
+    const Triangle* begin() const { return p_; } const Triangle* end() const { return p_ + n_; }
 };
 
 // Texture, entities.rs:86-91.  rgb.size() == 3*width*height
@@ -37,16 +61,23 @@ struct FlatOctree {
 };
 
 struct Model {
-    std::vector<Triangle> triangles;      // SceneData.triangles, push order
+    TriArray triangles;                   // SceneData.triangles, push order
     std::vector<rrt_material> materials;
     std::vector<Texture> textures;
     Box root{};
-    FlatOctree tree;
-    double read_ms = 0, parse_ms = 0, texture_ms = 0, octree_ms = 0;   // wall time of the set-up stages (reported by rrt_get_setup_times)
+    // The host copy of the octree is built on demand (host_tree(): rrt_model_get_info / rrt_model_get_octree, and raytracers created with
+    // RRT_FLAG_HOST_SETUP).  The default set-up builds the tree on the GPU inside rrt_raytracer_create (scene_build.hip) and never needs it.
+    mutable FlatOctree tree;
+    mutable std::mutex tree_mu;
+    mutable bool tree_ready = false;
+    double read_ms = 0, parse_ms = 0, texture_ms = 0;   // wall time of the set-up stages (reported by rrt_get_setup_times)
+    mutable double octree_ms = 0;                        // host octree build, when it ran
 };
+// builds m.tree on the host if it is not there yet (octree.cpp); throws Error{RRT_ERR_DEPTH} for a tree deeper than RRT_MAX_OCTREE_DEPTH
+const FlatOctree& host_tree(const Model& m);
 
 // octree.cpp
-void build_octree(const std::vector<Triangle>& tris, const Box& root, FlatOctree& out);
+void build_octree(const Triangle* tris, size_t n_tris, const Box& root, FlatOctree& out);
 
 // obj_loader.cpp -- throws rrt::Error
 struct Error { int status; std::string detail; };

@@ -358,7 +358,7 @@ struct Loader {
         if (trace) fprintf(stderr, "[loader] concat %.1f ms\n", since(tA));
         tA = now();
         // the faces before the first failing directive, each against the counts of its own line (get_triangle, utils.rs:253-343)
-        m.triangles.resize(stop_face);
+        m.triangles.resize_uninit(stop_face);
         std::vector<size_t> chunk_of_begin(n_chunks);
         parallel_ranges(n_chunks, 1, [&](size_t b, size_t e, size_t) {
             for (size_t c = b; c < e; c++) {
@@ -367,7 +367,7 @@ struct Loader {
                     const FaceRec& f = C.faces[k];
                     const uint64_t nv = off_v[c] + f.nv, nvt = off_vt[c] + f.nvt, nvn = off_vn[c] + f.nvn;
                     Triangle& tri = m.triangles[off_f[c] + k];
-                    tri.mat = face_mat[off_f[c] + k];
+                    tri.mat = face_mat[off_f[c] + k]; tri._pad = 0;
                     Vec3* P[3] = {&tri.v1, &tri.v2, &tri.v3}; Vec3* T[3] = {&tri.t1, &tri.t2, &tri.t3}; Vec3* N[3] = {&tri.n1, &tri.n2, &tri.n3};
                     for (int q = 0; q < 3; q++) {
                         if (f.bad_k == q) throw FaceError{off_f[c] + k, Error{RRT_ERR_PARSE, C.msgs[f.bad_msg]}};
@@ -389,8 +389,7 @@ struct Loader {
 }  // namespace
 
 void load_obj(const std::string& obj_path, const Box& root, Model& out) {
-    out = Model{};
-    out.root = root;
+    out.root = root;                       // (out is a freshly constructed Model: rrt_model_load_obj)
     size_t slash = obj_path.find_last_of('/');
     Loader L{slash == std::string::npos ? std::string() : obj_path.substr(0, slash + 1), out, {}, {}, {}, {}};
     using clk = std::chrono::steady_clock;
@@ -414,11 +413,10 @@ void load_obj(const std::string& obj_path, const Box& root, Model& out) {
     try { L.parse_obj(sv(map.p ? map.p : "", map.n)); }
     catch (const Loader::FaceError& fe) { throw fe.err; }
     const auto t2 = clk::now();
-    // the reference pushes each triangle into the octree as it is parsed (utils.rs:196); inserting them afterwards
-    // in the same order builds the same tree
-    build_octree(out.triangles, out.root, out.tree);
-    const auto t3 = clk::now();
-    out.read_ms = ms(t0, t1); out.parse_ms = ms(t1, t2) - out.texture_ms; out.octree_ms = ms(t2, t3);
+    // The reference pushes each triangle into the octree as it is parsed (utils.rs:196).  Inserting them afterwards in the same order builds the same
+    // tree, and here that happens where the tree is needed: on the GPU inside rrt_raytracer_create (scene_build.hip), or on the host when a getter
+    // or a RRT_FLAG_HOST_SETUP raytracer asks for it (host_tree, octree.cpp).
+    out.read_ms = ms(t0, t1); out.parse_ms = ms(t1, t2) - out.texture_ms;
 }
 
 }  // namespace rrt

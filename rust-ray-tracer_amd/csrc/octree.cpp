@@ -9,6 +9,7 @@
 // depends on this structure (ray.rs:116-167 is not an exact nearest-hit query), so nothing here is "improved".
 //
 // The descent is written as a loop over a growing node table; the GPU consumes the flattened form directly.
+#include <chrono>
 #include <cmath>
 #include <functional>
 
@@ -72,7 +73,10 @@ struct Builder {
         if (!touches(tb, box[0])) return;         // octree.rs:71-73: silently dropped
         static const uint32_t child_of[8] = {0, 1, 4, 5, 3, 2, 7, 6};   // index (x-half << 2 | y-half << 1 | z-half) -> child number of `half` above
         uint32_t node = 0;
-        for (;;) {
+        for (uint32_t level = 1;; level++) {
+            // (every level below RRT_MAX_OCTREE_DEPTH - 1 that a triangle reaches exists or is about to: a chain of coincident triangles would otherwise
+            //  be followed to its end -- quadratic in their number -- before the depth check could refuse it)
+            if (level > RRT_MAX_OCTREE_DEPTH) throw Error{RRT_ERR_DEPTH, "octree depth exceeds RRT_MAX_OCTREE_DEPTH (" + std::to_string(RRT_MAX_OCTREE_DEPTH) + "): coincident triangles? (octree.rs:79-92)"};
             tri_count[node] += 1;
             const bool leaf = first_child[node] == 0;
             if (leaf && own_count[node] == 0) { own_count[node] = 1; tri_node[tri] = node; return; }
@@ -88,13 +92,15 @@ struct Builder {
 
 }  // namespace
 
-void build_octree(const std::vector<Triangle>& tris, const Box& root, FlatOctree& out) {
+void build_octree(const Triangle* tris, size_t n_tris, const Box& root, FlatOctree& out) {
     Builder b;
-    b.tri_node.assign(tris.size(), Builder::kNowhere);
+    b.tri_node.assign(n_tris, Builder::kNowhere);
     b.add_node(root);                                 // Octree::new, octree.rs:23-39
-    std::vector<Box> tb(tris.size());
-    parallel_ranges(tris.size(), 1 << 15, [&](size_t lo, size_t hi, size_t) { for (size_t i = lo; i < hi; i++) tb[i] = triangle_box(tris[i]); });
-    for (uint32_t i = 0; i < tris.size(); i++) b.insert(i, tb[i]);   // insertion order decides the tree: serial by nature
+    std::vector<Box> tb(n_tris);
+    parallel_ranges(n_tris, 1 << 15, [&](size_t lo, size_t hi, size_t) { for (size_t i = lo; i < hi; i++) tb[i] = triangle_box(tris[i]); });
+    // One triangle after the other, as the reference does.  (The insertion is not serial by nature -- scene_build.hip builds the same tree level by
+    // level on the GPU, which is what rrt_raytracer_create uses; this loop serves the host-side getters and RRT_FLAG_HOST_SETUP.)
+    for (uint32_t i = 0; i < n_tris; i++) b.insert(i, tb[i]);
 
     const uint32_t n = (uint32_t)b.box.size();
     out.box = std::move(b.box);
@@ -106,7 +112,7 @@ void build_octree(const std::vector<Triangle>& tris, const Box& root, FlatOctree
     out.own_idx.assign(out.own_off[n], 0);
     {
         std::vector<uint32_t> fill(out.own_off.begin(), out.own_off.end() - 1);
-        for (uint32_t i = 0; i < tris.size(); i++) if (b.tri_node[i] != Builder::kNowhere) out.own_idx[fill[b.tri_node[i]]++] = i;
+        for (uint32_t i = 0; i < n_tris; i++) if (b.tri_node[i] != Builder::kNowhere) out.own_idx[fill[b.tri_node[i]]++] = i;
     }
 
     // depth (root = 1): children always have larger ids than their parent, so one forward sweep suffices
@@ -117,6 +123,20 @@ void build_octree(const std::vector<Triangle>& tris, const Box& root, FlatOctree
         for (uint32_t c = 0; c < 8; c++) depth[out.first_child[i] + c] = depth[i] + 1;
         if (depth[i] + 1 > out.max_depth) out.max_depth = depth[i] + 1;
     }
+}
+
+const FlatOctree& host_tree(const Model& m) {
+    std::lock_guard<std::mutex> lk(m.tree_mu);
+    if (!m.tree_ready) {
+        const auto t0 = std::chrono::steady_clock::now();
+        FlatOctree t;
+        build_octree(m.triangles.data(), m.triangles.size(), m.root, t);
+        if (t.max_depth > RRT_MAX_OCTREE_DEPTH) throw Error{RRT_ERR_DEPTH, "octree depth " + std::to_string(t.max_depth) + " exceeds RRT_MAX_OCTREE_DEPTH"};
+        m.tree = std::move(t);
+        m.octree_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        m.tree_ready = true;
+    }
+    return m.tree;
 }
 
 }  // namespace rrt

@@ -410,20 +410,21 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 }
 // Twelve f32 min-reductions at once, step by step across all twelve registers: dependent DPP operations are then 12 instructions apart and need
 // no wait states (only the first step follows ordinary VALU writes).  All inputs are finite or +-inf, never NaN.
-#define RRT_DPP12(ctrl)                                                                                              \
-    asm volatile("v_min_f32_dpp %0, %0, %0 " ctrl "\n\tv_min_f32_dpp %1, %1, %1 " ctrl "\n\tv_min_f32_dpp %2, %2, %2 " ctrl "\n\t"    \
+#define RRT_DPP12(pre, ctrl)                                                                                         \
+    asm volatile(pre "v_min_f32_dpp %0, %0, %0 " ctrl "\n\tv_min_f32_dpp %1, %1, %1 " ctrl "\n\tv_min_f32_dpp %2, %2, %2 " ctrl "\n\t"    \
                  "v_min_f32_dpp %3, %3, %3 " ctrl "\n\tv_min_f32_dpp %4, %4, %4 " ctrl "\n\tv_min_f32_dpp %5, %5, %5 " ctrl "\n\t"    \
                  "v_min_f32_dpp %6, %6, %6 " ctrl "\n\tv_min_f32_dpp %7, %7, %7 " ctrl "\n\tv_min_f32_dpp %8, %8, %8 " ctrl "\n\t"    \
                  "v_min_f32_dpp %9, %9, %9 " ctrl "\n\tv_min_f32_dpp %10, %10, %10 " ctrl "\n\tv_min_f32_dpp %11, %11, %11 " ctrl     \
                  : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]))
 __device__ __forceinline__ void wave_min12_f32(float (&x)[12]) {
-    asm volatile("s_nop 1" ::: "memory");
-    RRT_DPP12("row_shr:1 row_mask:0xf bank_mask:0xf");
-    RRT_DPP12("row_shr:2 row_mask:0xf bank_mask:0xf");
-    RRT_DPP12("row_shr:4 row_mask:0xf bank_mask:0xf");
-    RRT_DPP12("row_shr:8 row_mask:0xf bank_mask:0xf");
-    RRT_DPP12("row_bcast:15 row_mask:0xa bank_mask:0xf");
-    RRT_DPP12("row_bcast:31 row_mask:0xc bank_mask:0xf");
+    // (the wait states sit INSIDE the block that holds the first DPP read: an s_nop in a statement of its own can be scheduled away from it, and the
+    //  compiler's hazard recognizer does not look into inline asm -- the x[] producers may be the instructions directly before this block)
+    RRT_DPP12("s_nop 1\n\t", "row_shr:1 row_mask:0xf bank_mask:0xf");
+    RRT_DPP12("", "row_shr:2 row_mask:0xf bank_mask:0xf");
+    RRT_DPP12("", "row_shr:4 row_mask:0xf bank_mask:0xf");
+    RRT_DPP12("", "row_shr:8 row_mask:0xf bank_mask:0xf");
+    RRT_DPP12("", "row_bcast:15 row_mask:0xa bank_mask:0xf");
+    RRT_DPP12("", "row_bcast:31 row_mask:0xc bank_mask:0xf");
 #pragma unroll
     for (int i = 0; i < 12; i++) x[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x[i]), 63));
 }

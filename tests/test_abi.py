@@ -81,8 +81,12 @@ def test_round2_entry_points_validate_their_arguments_without_a_gpu(rrt, teapot)
     assert L.rrt_host_buffer_register(None, 0) == rrt.ERR_INVALID_ARG and L.rrt_host_buffer_unregister(None) == rrt.ERR_INVALID_ARG
     L.rrt_multi_destroy(None)                                           # a no-op, like free(NULL)
     t = rrt.CSetupTimes()
+    assert C.sizeof(rrt.CSetupTimes) == 72                              # nine doubles, include/rrt.h
+    _ = teapot.info                                                     # the host copy of the octree is built on demand (rrt_model_get_info)
     assert L.rrt_get_setup_times(teapot._h, None, C.byref(t)) == rrt.OK
-    assert t.parse_ms > 0 and t.texture_ms > 0 and t.octree_ms > 0 and t.index_ms == 0 and t.upload_ms == 0
+    assert t.parse_ms > 0 and t.texture_ms > 0 and t.octree_ms > 0 and t.index_ms == 0 and t.upload_ms == 0 and t.create_ms == 0
+    assert L.rrt_raytracer_get_octree(None, None, None, None, None, None, None) == rrt.ERR_INVALID_ARG
+    assert L.rrt_raytracer_get_buffer(None, 0, None, 0, None) == rrt.ERR_INVALID_ARG
     assert L.rrt_get_setup_times(None, None, None) == rrt.ERR_INVALID_ARG
 
 
@@ -91,5 +95,7 @@ def test_flag_constants_match_the_header(rrt):
     import re
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "rrt.h")).read()
     vals = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define RRT_FLAG_(\w+) (\d+)u", hdr)}
-    assert vals == {"NO_CULL": rrt.FLAG_NO_CULL, "LANE_FILTER": rrt.FLAG_LANE_FILTER, "BUNDLE_FILTER": rrt.FLAG_BUNDLE_FILTER, "RAY_WALK": rrt.FLAG_RAY_WALK}
+    assert vals == {"NO_CULL": rrt.FLAG_NO_CULL, "LANE_FILTER": rrt.FLAG_LANE_FILTER, "BUNDLE_FILTER": rrt.FLAG_BUNDLE_FILTER, "RAY_WALK": rrt.FLAG_RAY_WALK, "HOST_SETUP": rrt.FLAG_HOST_SETUP}
+    bufs = re.search(r"enum \{ (RRT_BUF_NODES.*?) \};", hdr, re.S).group(1)
+    assert tuple(b.strip().split(" ")[0][len("RRT_BUF_"):].lower() for b in bufs.split(",")) == rrt.BUFFERS
     assert rrt.VARIANT_NAMES == ("lane", "bundle", "ray")
