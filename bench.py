@@ -53,25 +53,103 @@ def algorithmic_flops(c: dict) -> float:
     return 52.0 * c["tri_tests"] + 24.0 * c["aabb_tests"] + 250.0 * c["hits_shaded"]
 
 
-def spawn_ranks(args, argv) -> int:
-    """`python bench.py --gpus N` outside a launcher: start the N ranks as fresh child processes (this process has not touched the GPU) and relay
-    rank 0's one JSON line."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.abspath(__file__)] + argv
-    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
-    line = None
-    for out in p.stdout:
-        s = out.strip()
-        if s.startswith("{") and '"metric"' in s:
-            line = s
-        elif s:
-            print(s, file=sys.stderr, flush=True)
-    rc = p.wait()
-    if line:
-        print(line, flush=True)
-    return rc if rc else (0 if line else 1)
+def _strip_opt(argv, name):
+    out, skip = [], False
+    for a in argv:
+        if skip: skip = False; continue
+        if a == name: skip = True; continue
+        if a.startswith(name + "="): continue
+        out.append(a)
+    return out
+
+
+def run_group(cmd, env, timeout):
+    """One group of fresh child processes under its own timeout.  Returns (json_line | None, rc | None, stderr tail, timed_out).  The children run in a
+    process group of their own; a group that does not finish is killed as a group (this process never touches the GPU, so it can always do that)."""
+    import signal, threading
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    line, tail = [None], []
+
+    def pump_out():
+        for out in p.stdout:
+            t = out.strip()
+            if t.startswith("{") and '"metric"' in t: line[0] = t
+            elif t: tail.append(t); del tail[:-40]
+
+    def pump_err():
+        for out in p.stderr:
+            t = out.rstrip()
+            if t:
+                tail.append(t); del tail[:-40]
+                print(t, file=sys.stderr, flush=True)
+    th = [threading.Thread(target=pump_out, daemon=True), threading.Thread(target=pump_err, daemon=True)]
+    for t in th: t.start()
+    timed_out = False
+    try:
+        rc = p.wait(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        timed_out = True
+        try:
+            os.killpg(p.pid, signal.SIGKILL)                  # exactly the process group started above
+        except ProcessLookupError:
+            pass
+        rc = p.wait()
+    for t in th: t.join(timeout=5)
+    return line[0], rc, tail, timed_out
+
+
+def supervise(args, argv) -> int:
+    """N > 1 (or RRT_BENCH_FORCE_DIST=1): this process stays GPU-free and runs every gather path as its OWN group of fresh child processes, one group
+    after the other, each under its own timeout -- `--gather auto`: the torch.distributed.gather choreography, then the library's RCCL gather.  A group
+    that does not finish is killed by this process; its last stage and stderr tail go into gather_paths.<path>.error and the other path's line is
+    printed.  rc != 0 only if no path finished.  Works in both launch modes: started plainly (`python bench.py --gpus N`: each group is one
+    torch.distributed.run) or as a rank under a launcher (the driver's `python -m torch.distributed.run ... bench.py --gpus N`: every rank supervises
+    its own children, which rendezvous on MASTER_PORT + 11 + k)."""
+    under_launcher = "WORLD_SIZE" in os.environ
+    rank = int(os.environ.get("RANK", "0"))
+    force_one = os.environ.get("RRT_BENCH_FORCE_DIST") == "1" and args.gpus == 1
+    paths = ["torch", "lib"] if args.gather == "auto" else [args.gather]
+    base = _strip_opt(argv, "--gather")
+    lines, info = {}, {}
+    for k, path in enumerate(paths):
+        timeout = args.lib_timeout if path == "lib" else args.torch_timeout
+        env = dict(os.environ)
+        child = [os.path.abspath(__file__)] + base + ["--gather", path, "--child"]
+        if under_launcher:
+            env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 11 + k)
+            cmd = [sys.executable] + child
+        elif force_one:
+            env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29533")) + k)
+            cmd = [sys.executable] + child
+        else:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port)] + child
+        t0 = time.time()
+        line, rc, tail, timed_out = run_group(cmd, env, timeout)
+        stage = next((t.split("[bench stage]", 1)[1].strip() for t in reversed(tail) if "[bench stage]" in t), None)
+        ok = (rc == 0) and (line is not None or rank != 0)
+        if ok:
+            if line is not None: lines[path] = json.loads(line)
+            info[path] = {"ok": True}
+        else:
+            why = f"timed out after {timeout:.0f} s and was killed by the supervisor" if timed_out else f"exited with rc {rc}" + ("" if line else " and printed no result")
+            info[path] = {"ok": False, "error": f"{path} gather group {why}; last stage: {stage or 'unknown'}; stderr tail: {' | '.join(tail[-4:])[-600:]}", "seconds": round(time.time() - t0, 1)}
+            print(f"[bench supervisor rank {rank}] {info[path]['error']}", file=sys.stderr, flush=True)
+    finished = [pth for pth in paths if info[pth]["ok"]]
+    if rank == 0 and finished:
+        summary = {}
+        for pth in paths:
+            o = lines.get(pth)
+            summary[pth] = ({"value": o["value"], "ms_per_step": o["ms_per_step"], "gather_ms": o.get("gather_ms"), "host_enqueue_ms_per_step": o["host_enqueue_ms_per_step"],
+                             "frames_in_flight": o.get("frames_in_flight"), "frame_checksum": o["frame_checksum"]} if o else {"error": info[pth].get("error")})
+        cands = [lines[pth] for pth in finished if pth in lines]
+        best = max(cands, key=lambda o: o["value"])
+        if "torch" in lines and "lib" in lines and lines["lib"]["frame_checksum"] != lines["torch"]["frame_checksum"]:
+            best = lines["torch"]; summary["lib"]["error"] = "frame differs from the torch path's"
+        best["gather_paths"] = summary
+        print(json.dumps(best), flush=True)
+    return 0 if finished else 1
 
 
 def main() -> None:
@@ -85,16 +163,24 @@ def main() -> None:
     ap.add_argument("--pipeline-depth", type=int, default=4, help="N > 1: frames in flight (gather + de-tiling of a frame overlap the tracing of the next); 0 = plain one-frame-at-a-time step")
     ap.add_argument("--gather", choices=("auto", "lib", "torch"), default="auto", help="N > 1: `lib` = the library's own RCCL gather (rrt_dist_create / rrt_multi_enqueue: partition, "
                     "gather and de-tiling behind the C ABI); `torch` = the same choreography issued from here with torch.distributed.gather; `auto` = K steps of each, "
-                    "torch first, the library under a watchdog, the faster one reported (both in `gather_paths`)")
-    ap.add_argument("--lib-timeout", type=float, default=120.0, help="--gather auto: seconds the library path may take before the torch result is reported alone")
+                    "each path in its own group of fresh child processes under its own timeout (supervise()), the faster one reported (both in `gather_paths`)")
+    ap.add_argument("--lib-timeout", type=float, default=180.0, help="N > 1: seconds the library-gather child group may take before the supervisor kills it")
+    ap.add_argument("--torch-timeout", type=float, default=300.0, help="N > 1: seconds the torch-gather child group may take before the supervisor kills it")
+    ap.add_argument("--child", action="store_true", help="internal: this process is one rank of ONE gather path's child group (started by the supervisor)")
     ap.add_argument("--walk", choices=("auto", "lane", "bundle", "ray"), default="auto", help="traversal variant: auto = the library measures all three on the second frame of a size (the product default); the others force one (developer A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-first-frame", action="store_true", help="skip the cold time-to-first-frame measurement (first_frame_ms)")
     ap.add_argument("--no-host-fb", action="store_true", help="skip the boundary-inclusive rrt_render timings (frame_ms_host_fb)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the bounded cpu_baseline leg (3 samples)")
     args = ap.parse_args()
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("RRT_BENCH_FORCE_DIST") != "1":
-        raise SystemExit(spawn_ranks(args, sys.argv[1:]))
+    if (args.gpus > 1 or os.environ.get("RRT_BENCH_FORCE_DIST") == "1") and not args.child:
+        raise SystemExit(supervise(args, sys.argv[1:]))            # GPU-free from here on: every gather path runs in fresh child processes
+    if args.child and args.gather == "auto":
+        raise SystemExit("bench.py --child needs an explicit --gather torch|lib")
+
+    def stage(msg):
+        print(f"[bench stage] {msg}", file=sys.stderr, flush=True)
 
     # stdout carries exactly ONE line, the JSON: RCCL prints a version banner and gloo its connection notes to fd 1 while the process group
     # comes up, so fd 1 points at stderr until the result is printed.
@@ -145,7 +231,7 @@ def main() -> None:
     rt = rrt.RayTracer(sd, lights, rrt.DEFAULT_ORIGIN, device=local_rank, box_filter=None if args.walk == "auto" else args.walk)
     setup_wall_ms = (time.perf_counter() - t_setup) * 1e3
     setup = {k: round(v, 2) for k, v in rt.setup_times().items()}
-    setup["total_ms"] = round(sum(setup.values()), 2); setup["wall_ms_incl_binding"] = round(setup_wall_ms, 2)
+    setup["total_ms"] = round(sum(v for k, v in setup.items() if k not in ("create_ms", "gpu_setup")), 2); setup["wall_ms_incl_binding"] = round(setup_wall_ms, 2)
 
     fb = torch.zeros((H, W), dtype=torch.int32, device="cuda")
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -178,7 +264,6 @@ def main() -> None:
         def lib_init():
             """The library's own gather: (a) local -- bind RCCL inside the library (dlopen), no communication; the ranks agree; (b) collective --
             ncclCommInitRank with rank 0's id."""
-            lib_state["stage"] = "binding RCCL inside the library (dlopen)"
             ok, err, uid = 1, None, None
             try:
                 uid = rrt.MultiGpu.unique_id()
@@ -191,7 +276,7 @@ def main() -> None:
                 return None
             idt = torch.frombuffer(bytearray(uid), dtype=torch.uint8).cuda()
             dist.broadcast(idt, src=0)
-            lib_state["stage"] = "ncclCommInitRank (rrt_dist_create)"
+            stage("library gather: ncclCommInitRank (rrt_dist_create)")
             return rrt.MultiGpu.dist(rt, rank, world, bytes(idt.cpu().numpy().tobytes()), frames_in_flight=DEPTH)   # collective
         ok = 1
         try:
@@ -265,10 +350,8 @@ def main() -> None:
                 simple_step(i) if simple[0] else pipelined_step(i)
             except Exception as e:                               # noqa: BLE001 -- collectives are in flight: no safe fallback from here
                 print(f"[bench rank {rank}] step failed after collectives were issued ({type(e).__name__}: {e}); aborting", file=sys.stderr, flush=True)
-                try:
-                    dist.destroy_process_group()
-                finally:
-                    os._exit(3)
+                stage(f"torch gather path: step failed after collectives were issued ({type(e).__name__})")
+                raise SystemExit(3)                              # non-zero; should teardown hang, the supervisor's timeout ends the group
 
         def torch_fence():
             set_stream(default_stream)
@@ -332,7 +415,7 @@ def main() -> None:
         in_lib = gather_label == "lib"
         ms_per_step = elapsed / args.steps * 1e3
         frame = m["frame"]
-        workload_key = f"{'soup' + str(sd.info['n_tris']) if scene_name.startswith('soup') else scene_name}@{W}x{H}"
+        workload_key = f"{'soup' + str(rt.info['n_tris']) if scene_name.startswith('soup') else scene_name}@{W}x{H}"
 
         # --- boundary-inclusive frame: rrt_render into a HOST framebuffer, as the Rust host's Canvas.buffer receives it (engine.rs:127,246-250)
         host_fb = None
@@ -357,6 +440,30 @@ def main() -> None:
             host_fb = {"frame_ms_host_fb": round(registered, 4), "frame_ms_host_fb_pageable": round(pageable, 4), "frames": n_host, "identical_to_device_frame": same,
                        "note": "wall time of the blocking rrt_render(rt, w, h, host_fb): kernel + device->host copy; `frame_ms_host_fb` with the caller's buffer page-locked "
                                "(rrt_host_buffer_register: one DMA), `..._pageable` through the library's pinned staging + pipelined host copy"}
+
+        # --- time to FIRST frame (the reference renders one frame per run, main.rs:59-76): a host that has parsed the scene itself hands the triangle
+        # arrays over (rrt_model_from_arrays), creates the raytracer (upload + octree + index built on the GPU) and renders one frame into a pageable
+        # host framebuffer -- cold scene, cold variant choice, warm process (the HIP context exists; hip_init_ms is a one-off of the process).
+        first = None
+        if world == 1 and not multi and not args.no_first_frame:
+            pos, uv, nrm, mat = sd.triangles(); mats_, texs_ = sd.materials(), sd.textures()
+            def cold(host_setup):
+                t0 = time.perf_counter()
+                sd2 = rrt.SceneData.from_arrays(pos, uv, nrm, mat, mats_, texs_)
+                t1 = time.perf_counter()
+                rt2 = rrt.RayTracer(sd2, lights, rrt.DEFAULT_ORIGIN, device=local_rank, host_setup=host_setup)
+                t2 = time.perf_counter()
+                f = rt2.render(W, H)
+                t3 = time.perf_counter()
+                st = rt2.setup_times()
+                return {"first_frame_ms": round((t3 - t0) * 1e3, 2), "model_from_arrays_ms": round((t1 - t0) * 1e3, 2), "raytracer_create_ms": round((t2 - t1) * 1e3, 2),
+                        "first_render_ms": round((t3 - t2) * 1e3, 2), "octree_ms": round(st["octree_ms"], 2), "index_ms": round(st["index_ms"], 2), "upload_ms": round(st["upload_ms"], 2),
+                        "variant": rrt.VARIANT_NAMES[rt2.last_stats()["filter_variant"]], "identical_to_steady_frame": bool(np.array_equal(f, frame))}
+            runs = [cold(False) for _ in range(3)]
+            first = dict(sorted(runs, key=lambda r: r["first_frame_ms"])[1], runs_ms=[r["first_frame_ms"] for r in runs])
+            first["host_setup"] = cold(True)
+            first["note"] = ("median of 3 cold runs: rrt_model_from_arrays -> rrt_raytracer_create (GPU set-up: pinned-staging upload, octree.rs:41-241 level-parallel on the device, index, "
+                             "records) -> first rrt_render into a pageable host framebuffer; `host_setup` = the same with RRT_FLAG_HOST_SETUP (round-2 path), once")
 
         # --- work counters for the reference algorithm's flop count (oracle counters; committed for the headline config, else scaled from the CPU sample)
         counters, counters_src = None, None
@@ -465,7 +572,7 @@ def main() -> None:
                "config": {"workload": f"{scene_name} {W}x{H}, 4 sub-samples/pixel, shadow rays + depth-5 mirror reflection, f64",
                           "rays_primary_per_frame": rays_primary,
                           "partition": "single launch" if not multi else f"8x8-pixel tiles round-robin over {world} GPUs + RCCL gather to GPU 0, " + (f"inside the library (rrt_multi_enqueue), {DEPTH} frames in flight" if in_lib else "torch.distributed.gather, " + ("one frame at a time" if simple[0] else f"{DEPTH} frames in flight (one stream per slot)")),
-                          "octree_nodes": sd.info["n_nodes"], "triangles": sd.info["n_tris"], "filter_variant": rrt.VARIANT_NAMES[rt.last_stats()["filter_variant"]]},
+                          "octree_nodes": rt.info["n_nodes"], "triangles": rt.info["n_tris"], "filter_variant": rrt.VARIANT_NAMES[rt.last_stats()["filter_variant"]]},
                "frame_ms": round(ms_per_step, 4), "kernel_ms": round(kernel_ms, 4), "host_enqueue_ms_per_step": round(host_enqueue_ms, 4), "setup_ms": setup,
                **({"rehearsal": "gloo on one GPU: NOT a benchmark result"} if rehearsal else {}),
                "frame_checksum": int(np.bitwise_xor.reduce(frame.ravel().astype(np.uint64) * np.arange(1, frame.size + 1, dtype=np.uint64)))}
@@ -474,6 +581,8 @@ def main() -> None:
                         "kernel_ms_per_rank_max": round(kernel_ms_max, 4), "gather_ms": round(gather_ms, 4) if gather_ms is not None else None})
         if host_fb is not None:
             out.update({"frame_ms_host_fb": host_fb["frame_ms_host_fb"], "host_fb": host_fb})
+        if first is not None:
+            out.update({"first_frame_ms": first["first_frame_ms"], "first_frame": first})
         out["roofline"] = roofline
         if cpu is not None:
             out["cpu_baseline"] = cpu
@@ -485,72 +594,48 @@ def main() -> None:
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
 
-    # ---- the measurement(s)
-    paths = {}
+    # ---- the measurement.  N > 1: this process is one rank of ONE gather path's child group (the GPU-free supervisor runs the paths one after the
+    # other in fresh processes and merges their lines): it either finishes or exits non-zero -- no in-process watchdog, no forced zero exit with the GPU held.
     if not multi:
         res = measure(step, fence)
         if rank == 0: emit(build_out(res, None))
+    elif args.gather == "torch" or rehearsal:
+        stage("torch.distributed.gather path: timed steps")
+        res = measure(torch_step, torch_fence)
+        if rank == 0:
+            out = build_out(res, "torch")
+            out["frames_in_flight"] = 1 if simple[0] else DEPTH
+            emit(out)
     else:
-        first = "lib" if args.gather == "lib" else "torch"
-        out_first = None
-        if first == "torch":
-            res = measure(torch_step, torch_fence)
-            if rank == 0:
-                out_first = build_out(res, "torch")
-                paths["torch"] = {"value": out_first["value"], "ms_per_step": out_first["ms_per_step"], "gather_ms": out_first.get("gather_ms"), "host_enqueue_ms_per_step": out_first["host_enqueue_ms_per_step"],
-                                  "frames_in_flight": 1 if simple[0] else DEPTH}
-        if args.gather in ("auto", "lib") and not rehearsal:
-            # the library's gather has the cheaper host side (one C call per frame); under `auto` it runs behind the torch result, guarded by a
-            # watchdog: if it does not finish in time the torch line is printed alone (with the stage it hung in) and the process ends cleanly
-            import threading
-            finished = threading.Event()
+        # the library's own gather (rrt_dist_create / rrt_multi_enqueue): the cheaper host side, one C call per frame
+        stage("library gather: binding RCCL inside the library (dlopen)")
+        if os.environ.get("RRT_BENCH_TEST_HANG") == "lib":      # test hook (tests/test_gpu_parity.py): a library path that never finishes
+            stage("library gather: test hook RRT_BENCH_TEST_HANG=lib, sleeping before rrt_dist_create")
+            time.sleep(1e6)
+        lib_mg = lib_init()
+        if lib_mg is None:
+            dist.destroy_process_group()
+            raise SystemExit(f"bench.py: library gather could not be set up: {lib_state['error']}")
+        stage("library gather: first frames through rrt_multi_enqueue")
+        lib_enqueue = lib_mg.bind_enqueue(fb if rank == 0 else None, W, H)
 
-            def watchdog():
-                if finished.wait(args.lib_timeout): return
-                msg = f"library gather did not finish within {args.lib_timeout:.0f} s (stage: {lib_state['stage']})"
-                print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
-                if rank == 0 and out_first is not None:
-                    out_first["gather_paths"] = dict(paths, lib={"error": msg})
-                    emit(out_first)
-                os._exit(0 if out_first is not None or rank != 0 else 4)
-            if args.gather == "auto":
-                threading.Thread(target=watchdog, daemon=True).start()
-            lib_mg = lib_init()
-            out_lib = None
-            if lib_mg is not None:
-                lib_state["stage"] = "first frames through rrt_multi_enqueue"
-                lib_enqueue = lib_mg.bind_enqueue(fb if rank == 0 else None, W, H)
+        def lib_step(i):
+            lib_enqueue()                                # trace -> grouped RCCL send/recv to rank 0 -> de-tile, all enqueued inside the library
 
-                def lib_step(i):
-                    lib_enqueue()                                # trace -> grouped RCCL send/recv to rank 0 -> de-tile, all enqueued inside the library
-
-                def lib_fence():
-                    set_stream(default_stream)
-                    lib_mg.sync()
-                    torch.cuda.synchronize()
-                    dist.barrier()
-                    torch.cuda.synchronize()
-                for _ in range(DEPTH): lib_step(None)
-                lib_fence()
-                lib_state["stage"] = "timed steps"
-                res = measure(lib_step, lib_fence, lib=lib_mg)
-                if rank == 0:
-                    out_lib = build_out(res, "lib")
-                    paths["lib"] = {"value": out_lib["value"], "ms_per_step": out_lib["ms_per_step"], "gather_ms": out_lib.get("gather_ms"), "host_enqueue_ms_per_step": out_lib["host_enqueue_ms_per_step"],
-                                    "frames_in_flight": DEPTH, "same_frame_as_torch_path": (out_first is None or out_lib["frame_checksum"] == out_first["frame_checksum"])}
-            else:
-                paths["lib"] = {"error": lib_state["error"]}
-            finished.set()
-            if rank == 0:
-                best = out_lib if (out_lib is not None and (out_first is None or (out_lib["value"] >= out_first["value"] and paths["lib"].get("same_frame_as_torch_path", True)))) else out_first
-                if best is None:
-                    raise SystemExit(f"bench.py: no N > 1 path completed ({paths})")
-                best["gather_paths"] = paths
-                emit(best)
-        elif rank == 0:
-            out_first["gather_paths"] = paths
-            emit(out_first)
-
+        def lib_fence():
+            set_stream(default_stream)
+            lib_mg.sync()
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+        for _ in range(DEPTH): lib_step(None)
+        lib_fence()
+        stage("library gather: timed steps")
+        res = measure(lib_step, lib_fence, lib=lib_mg)
+        if rank == 0:
+            out = build_out(res, "lib")
+            out["frames_in_flight"] = DEPTH
+            emit(out)
 
     if multi:
         dist.barrier()

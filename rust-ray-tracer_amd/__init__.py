@@ -128,6 +128,14 @@ def lib() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: the HIP extension was not built (run `python -c 'import __graft_entry__ as g; g.build()'`). "
                               "There is no CPU fallback.")
+        # One HIP runtime per process.  The PyTorch wheel bundles its own libamdhip64.so (soname libamdhip64.so.7, the name this library needs), so
+        # whichever is loaded FIRST serves both; loaded second, torch would bring up a second runtime by file path and find "No HIP GPUs".  Tests and
+        # bench.py use torch for device buffers, so it goes first here (RRT_NO_TORCH_PRELOAD=1: a host without torch in the process).
+        if os.environ.get("RRT_NO_TORCH_PRELOAD") != "1":
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)
@@ -309,6 +317,13 @@ class RayTracer:
         h, self._h = getattr(self, "_h", None), None
         if h and _lib is not None:
             _lib.rrt_raytracer_destroy(h)
+
+    @property
+    def info(self) -> dict:
+        """rrt_model_info of the octree this raytracer's GPU set-up built (no host-side tree is built for it)."""
+        info = CModelInfo()
+        _check(lib().rrt_raytracer_get_octree(self._h, C.byref(info), None, None, None, None, None), "rrt_raytracer_get_octree")
+        return {k: getattr(info, k) for k, _ in CModelInfo._fields_}
 
     def octree(self) -> dict:
         """The octree this raytracer's GPU set-up built (rrt_raytracer_get_octree): same dict as SceneData.octree(), plus "info"."""

@@ -43,11 +43,7 @@ struct rrt_raytracer {
     rrt::GpuScene gs{};                                   // GPU set-up: the device-side octree and the sizes of the scene buffers
     rrt_model_info tree_info{};                           // GPU set-up: what rrt_model_get_info reports, from the device-built tree
     struct Buf { const void* p = nullptr; size_t bytes = 0; } bufs[16];   // rrt_raytracer_get_buffer
-    hipStream_t own_stream = nullptr;   // rrt_render's stream (non-blocking: independent of the legacy default stream)
-    void* staging = nullptr;         // pinned host staging for callers whose framebuffer is pageable memory
-    size_t staging_bytes = 0;
-    static constexpr int kCopyChunks = 8;
-    hipEvent_t chunk_ev[kCopyChunks] = {};
+    hipStream_t own_stream = nullptr;   // rrt_render's stream: the device's shared set-up stream (scene_build.hip: setup_stream; not owned)
     uint32_t tuned_w = 0, tuned_h = 0, tuned_world = 0;   // frame size the variant below belongs to
     uint32_t size_frames = 0;        // frames rendered at that size so far
     bool size_measured = false;      // ... and whether the variants have been timed on it (second frame of a size)
@@ -322,11 +318,13 @@ int rrt_model_from_arrays(uint32_t n_tris, const double* pos, const double* uv, 
         M.root = default_root(root);
         M.materials.assign(mats, mats + n_mats);
         M.textures.resize(n_tex);
-        for (uint32_t i = 0; i < n_tex; i++) {
-            if (!tex[i].rgb) throw Error{RRT_ERR_INVALID_ARG, "null texture data"};
-            M.textures[i].width = tex[i].width; M.textures[i].height = tex[i].height;
-            M.textures[i].rgb.assign(tex[i].rgb, tex[i].rgb + (size_t)3 * tex[i].width * tex[i].height);
-        }
+        for (uint32_t i = 0; i < n_tex; i++) if (!tex[i].rgb) throw Error{RRT_ERR_INVALID_ARG, "null texture data"};
+        parallel_ranges(n_tex, 1, [&](size_t lo, size_t hi, size_t) {
+            for (size_t i = lo; i < hi; i++) {
+                M.textures[i].width = tex[i].width; M.textures[i].height = tex[i].height;
+                M.textures[i].rgb.assign(tex[i].rgb, tex[i].rgb + (size_t)3 * tex[i].width * tex[i].height);
+            }
+        });
         M.triangles.resize_uninit(n_tris);
         parallel_ranges(n_tris, 1 << 14, [&](size_t lo, size_t hi, size_t) {
             auto rd = [](const double* p) { Vec3 v; v.x = p[0]; v.y = p[1]; v.z = p[2]; return v; };
@@ -550,9 +548,10 @@ void setup_on_host(rrt_raytracer* rt, const Model& M, rrt_vec3 origin, const rrt
 void setup_on_gpu(rrt_raytracer* rt, const Model& M, rrt_vec3 origin, const rrt_options& o, uint32_t& max_depth) {
     using clk = std::chrono::steady_clock;
     const auto t0 = clk::now();
+    const bool trace = std::getenv("RRT_SETUP_TRACE") != nullptr;
+    auto lap = [&, last = t0](const char* what) mutable { if (trace) { const auto n = clk::now(); fprintf(stderr, "[create]     %-34s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - last).count()); last = n; } };
     hipStream_t st = nullptr;
-    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } sg{st};
+    try { st = (hipStream_t)setup_stream(); } catch (const HipBuildFail& f) { throw HipFail{(hipError_t)f.hip_error, f.what}; }
     {   // textures + small tables: one allocation
         size_t need = (size_t)1 << 16;
         for (auto& t : M.textures) need += t.rgb.size() + 256;
@@ -561,6 +560,7 @@ void setup_on_gpu(rrt_raytracer* rt, const Model& M, rrt_vec3 origin, const rrt_
         rt->allocs.push_back(rt->arena);
         rt->arena_bytes = need;
     }
+    lap("stream, table arena");
     std::vector<DevTexture> texs; std::vector<DevMaterial> mats;
     GpuScene& G = rt->gs;
     const double org[3] = {origin.x, origin.y, origin.z};
@@ -568,7 +568,9 @@ void setup_on_gpu(rrt_raytracer* rt, const Model& M, rrt_vec3 origin, const rrt_
     catch (const HipBuildFail& f) { if (G.scene_alloc) { (void)hipFree(G.scene_alloc); G.scene_alloc = nullptr; } throw HipFail{(hipError_t)f.hip_error, f.what}; }
     catch (...) { if (G.scene_alloc) { (void)hipFree(G.scene_alloc); G.scene_alloc = nullptr; } throw; }
     rt->allocs.push_back(G.scene_alloc);
+    lap("gpu_build_scene");
     upload_materials_and_textures(rt, M, st, texs, mats);
+    lap("texture upload enqueued");
     max_depth = G.max_depth;
     DevScene& S = rt->scene;
     S.nodes = G.nodes; S.geom = G.geom; S.attr = G.attr; S.supers = G.supers; S.cboxes = G.cboxes; S.child_boxes = G.child_boxes; S.tboxes = G.tboxes; S.suspects = G.suspects;
@@ -597,6 +599,7 @@ void setup_on_gpu(rrt_raytracer* rt, const Model& M, rrt_vec3 origin, const rrt_
     S.n_nodes = G.n_nodes; S.n_slots = G.n_in_tree; S.n_mats = (uint32_t)mats.size(); S.n_tex = (uint32_t)texs.size();
     S.fc_mask = G.inline_leaves ? 0x00FFFFFFu : 0xFFFFFFFFu;
     HIP_TRY(hipStreamSynchronize(st));
+    lap("final synchronise");
     rt->octree_ms = G.ms_octree; rt->index_ms = G.ms_index;
     rt->upload_ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count() - G.ms_octree - G.ms_index;   // uploads, allocations, synchronisation
     rrt_model_info& I = rt->tree_info;
@@ -704,9 +707,6 @@ void rrt_raytracer_destroy(rrt_raytracer* rt) {
         (void)hipSetDevice(rt->device);
         for (void* p : rt->allocs) (void)hipFree(p);
         if (rt->host_fb) (void)hipFree(rt->host_fb);
-        if (rt->staging) (void)hipHostFree(rt->staging);
-        for (auto& e : rt->chunk_ev) if (e) (void)hipEventDestroy(e);
-        if (rt->own_stream) (void)hipStreamDestroy(rt->own_stream);
         if (rt->ev0) (void)hipEventDestroy(rt->ev0);
         if (rt->ev1) (void)hipEventDestroy(rt->ev1);
         (void)hipSetDevice(prev);
@@ -788,7 +788,7 @@ int rrt_render(rrt_raytracer* rt, uint32_t width, uint32_t height, uint32_t* out
             HIP_TRY(hipMalloc(&rt->host_fb, bytes));
             rt->host_fb_bytes = bytes;
         }
-        if (!rt->own_stream) HIP_TRY(hipStreamCreateWithFlags(&rt->own_stream, hipStreamNonBlocking));
+        if (!rt->own_stream) { try { rt->own_stream = (hipStream_t)setup_stream(); } catch (const HipBuildFail& f) { throw HipFail{(hipError_t)f.hip_error, f.what}; } }
         const int rc = rrt_render_device(rt, width, height, rt->host_fb, rt->own_stream);
         if (rc != RRT_OK) return rc;
         // Is the caller's framebuffer page-locked (rrt_host_buffer_register, hipHostMalloc, ...)?  Then one asynchronous DMA into it.
@@ -800,26 +800,8 @@ int rrt_render(rrt_raytracer* rt, uint32_t width, uint32_t height, uint32_t* out
             HIP_TRY(hipStreamSynchronize(rt->own_stream));                 // blocking: the frame is in out_fb on return
             return RRT_OK;
         }
-        // Pageable framebuffer: DMA into pinned staging in row chunks and copy each chunk out while the next ones are still in flight
-        // (a pageable hipMemcpy stages through the runtime's own bounce buffers serially: 2.3 ms per 1080p frame against 1.0 ms of tracing).
-        if (rt->staging_bytes < bytes) {
-            if (rt->staging) { (void)hipHostFree(rt->staging); rt->staging = nullptr; rt->staging_bytes = 0; }
-            HIP_TRY(hipHostMalloc(&rt->staging, bytes, hipHostMallocDefault));
-            rt->staging_bytes = bytes;
-        }
-        for (auto& e : rt->chunk_ev) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        const int n_chunks = bytes >= (size_t)(1u << 20) ? rrt_raytracer::kCopyChunks : 1;
-        const size_t rows_per = ((size_t)height + n_chunks - 1) / n_chunks, row_bytes = sizeof(uint32_t) * (size_t)width;
-        for (int c = 0; c < n_chunks; c++) {
-            const size_t r0 = std::min<size_t>(height, c * rows_per), r1 = std::min<size_t>(height, (c + 1) * rows_per);
-            if (r1 > r0) HIP_TRY(hipMemcpyAsync((char*)rt->staging + r0 * row_bytes, (const char*)rt->host_fb + r0 * row_bytes, (r1 - r0) * row_bytes, hipMemcpyDeviceToHost, rt->own_stream));
-            HIP_TRY(hipEventRecord(rt->chunk_ev[c], rt->own_stream));
-        }
-        for (int c = 0; c < n_chunks; c++) {
-            const size_t r0 = std::min<size_t>(height, c * rows_per), r1 = std::min<size_t>(height, (c + 1) * rows_per);
-            HIP_TRY(hipEventSynchronize(rt->chunk_ev[c]));
-            if (r1 > r0) std::memcpy((char*)out_fb + r0 * row_bytes, (const char*)rt->staging + r0 * row_bytes, (r1 - r0) * row_bytes);
-        }
+        // Pageable framebuffer: through the device's pinned staging ring, chunk DMAs running ahead of the copies out (scene_build.hip)
+        try { staged_download(out_fb, rt->host_fb, bytes, rt->own_stream); } catch (const HipBuildFail& f) { throw HipFail{(hipError_t)f.hip_error, f.what}; }
         return RRT_OK;
     });
 }

@@ -17,6 +17,8 @@
 // final node id (rocPRIM radix sort; the classification, commit and index kernels below are hand-written).
 #include <cfloat>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include <hip/hip_runtime.h>
@@ -61,12 +63,18 @@ struct Oct {
     double rlo[3], rhi[3];
 };
 
-// Lanes hold increasing triangle indices.  Arrivals at the same node within a wave are merged before they reach memory: the upper levels have few
-// nodes (the root: one), and a million same-address atomics would serialise in one L2 channel.
-__device__ __forceinline__ void arrive(uint32_t* mn, uint32_t* count, uint32_t node, uint32_t t, bool active) {
-    const int lane = threadIdx.x & 63;
+// Arrivals are recorded per node as (smallest index, count).  The upper levels have few nodes (the root: one; then 8, 64, 512): a million atomics
+// on a handful of addresses serialise in the L2 (measured: 1.8 ms per kernel on the 1 M soup's levels 1-3), so every workgroup first merges its
+// arrivals in LDS (ds_min / ds_add) and sends one atomic per node it touched; levels with more than kLdsNodes nodes go to memory directly (merged
+// within the wave where neighbouring triangles share a node).  min and + commute: the result does not depend on the order anything lands in.
+constexpr int kOctBlock = 1024;                 // threads per workgroup of the three per-triangle octree kernels
+constexpr uint32_t kLdsNodes = 1024;            // a level of at most this many nodes is merged in LDS
+constexpr unsigned kOctMaxGrid = 128;           // workgroups (grid-stride over the triangles): few, so that few partial results reach memory
+
+__device__ __forceinline__ void arrive_direct(uint32_t* mn, uint32_t* count, uint32_t node, uint32_t t, bool active) {
+    const int lane = threadIdx.x & 63;          // lanes hold increasing triangle indices: the lowest lane of a group has its minimum
     bool pending = active;
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < 4; ++it) {
         const unsigned long long pm = __ballot(pending);
         if (!pm) break;
         const int leader = __ffsll((long long)pm) - 1;
@@ -74,39 +82,64 @@ __device__ __forceinline__ void arrive(uint32_t* mn, uint32_t* count, uint32_t n
         const bool mine = pending && node == n0;
         const unsigned long long same = __ballot(mine);
         if (mine) {
-            if (lane == leader) { atomicMin(&mn[n0], t); if (count) atomicAdd(&count[n0], (uint32_t)__popcll(same)); }   // the leader is the lowest lane: its t is the group's minimum
+            if (lane == leader) { atomicMin(&mn[n0], t); if (count) atomicAdd(&count[n0], (uint32_t)__popcll(same)); }
             pending = false;
         }
     }
     if (pending) { atomicMin(&mn[node], t); if (count) atomicAdd(&count[node], 1u); }
 }
-__device__ __forceinline__ void count_wave(uint32_t* ctr, bool flag) {
-    const unsigned long long m = __ballot(flag);
-    if (m && (threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(ctr, (uint32_t)__popcll(m));
+struct LdsMerge {                               // one level's nodes [base, base + count) merged per workgroup
+    uint32_t* s_min; uint32_t* s_cnt; uint32_t base, count; bool on;
+    __device__ __forceinline__ void begin(uint32_t* smin, uint32_t* scnt, uint32_t base_, uint32_t count_) {
+        s_min = smin; s_cnt = scnt; base = base_; count = count_; on = count_ <= kLdsNodes;
+        if (on) for (uint32_t k = threadIdx.x; k < count; k += blockDim.x) { s_min[k] = kNone; s_cnt[k] = 0u; }
+        __syncthreads();
+    }
+    __device__ __forceinline__ void add(uint32_t* gmin, uint32_t* gcnt, uint32_t node, uint32_t t, bool active) {
+        if (on) { if (active) { atomicMin(&s_min[node - base], t); atomicAdd(&s_cnt[node - base], 1u); } }
+        else arrive_direct(gmin, gcnt, node, t, active);
+    }
+    __device__ __forceinline__ void flush(uint32_t* gmin, uint32_t* gcnt) {
+        __syncthreads();
+        if (on) for (uint32_t k = threadIdx.x; k < count; k += blockDim.x) if (s_cnt[k]) { atomicMin(&gmin[base + k], s_min[k]); if (gcnt) atomicAdd(&gcnt[base + k], s_cnt[k]); }
+    }
+};
+__device__ __forceinline__ void count_block(uint32_t* ctr, uint32_t* s_total, uint32_t mine) {   // (s_total zeroed and synchronised by the caller)
+    if (mine) atomicAdd(s_total, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && *s_total) atomicAdd(ctr, *s_total);
 }
 
-__global__ void __launch_bounds__(kBlock) k_oct_init(Oct S) {
-    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
-    bool act = false;
-    if (t < S.n) {
+__global__ void __launch_bounds__(kOctBlock) k_oct_init(Oct S) {
+    __shared__ uint32_t s_min[1], s_cnt[1], s_total;
+    if (threadIdx.x == 0) s_total = 0u;
+    LdsMerge M; M.begin(s_min, s_cnt, 0u, 1u);
+    uint32_t n_act = 0;
+    for (uint32_t t = blockIdx.x * kOctBlock + threadIdx.x; t < S.n; t += gridDim.x * kOctBlock) {
         const Triangle& T = S.tris[t];
         // Aabb::from_triangle, aabb.rs:25-47 (f64::min/max == fmin/fmax)
         const double lo[3] = {fmin(T.v1.x, fmin(T.v2.x, T.v3.x)), fmin(T.v1.y, fmin(T.v2.y, T.v3.y)), fmin(T.v1.z, fmin(T.v2.z, T.v3.z))};
         const double hi[3] = {fmax(T.v1.x, fmax(T.v2.x, T.v3.x)), fmax(T.v1.y, fmax(T.v2.y, T.v3.y)), fmax(T.v1.z, fmax(T.v2.z, T.v3.z))};
         bool touch = true;                                       // Aabb::intersects, aabb.rs:49-60 (inclusive)
         for (int k = 0; k < 3; k++) { S.tbox[6 * (size_t)t + k] = lo[k]; S.tbox[6 * (size_t)t + 3 + k] = hi[k]; if (hi[k] < S.rlo[k] || lo[k] > S.rhi[k]) touch = false; }
-        act = touch;
         S.cur[t] = touch ? 0u : kNone; S.own[t] = kNone; S.trig[t] = 0u;
+        if (touch) { atomicMin(&s_min[0], t); n_act++; }
     }
-    arrive(S.first, S.cnt, 0u, t, act);
-    count_wave(&S.ctr[1], act);
+    if (n_act) atomicAdd(&s_cnt[0], n_act);
+    M.flush(S.first, S.cnt);
+    count_block(&S.ctr[1], &s_total, n_act);
 }
 
-__global__ void __launch_bounds__(kBlock) k_oct_second(Oct S) {
-    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
-    const uint32_t m = t < S.n ? S.cur[t] : kNone;
-    const bool cand = m != kNone && S.first[m] != t;
-    arrive(S.second, nullptr, cand ? m : 0u, t, cand);
+__global__ void __launch_bounds__(kOctBlock) k_oct_second(Oct S, uint32_t lb, uint32_t le) {   // second-smallest arrival of every node of the level [lb, le)
+    __shared__ uint32_t s_min[kLdsNodes], s_cnt[kLdsNodes];
+    LdsMerge M; M.begin(s_min, s_cnt, lb, le - lb);
+    const uint32_t n_round = (S.n + 63u) & ~63u;                 // whole waves stay in the loop (arrive_direct uses wave ballots)
+    for (uint32_t t = blockIdx.x * kOctBlock + threadIdx.x; t < n_round; t += gridDim.x * kOctBlock) {
+        const uint32_t m = t < S.n ? S.cur[t] : kNone;
+        const bool cand = m != kNone && S.first[m] != t;
+        M.add(S.second, nullptr, cand ? m : lb, t, cand);
+    }
+    M.flush(S.second, nullptr);
 }
 
 // children in the reference's order BBL,BFL,BFR,BBR,TBL,TFL,TFR,TBR (octree.rs:216-225): (x-half, y-half, z-half), 0 = [lo,mid], 1 = [mid,hi]
@@ -128,26 +161,34 @@ __global__ void __launch_bounds__(kBlock) k_oct_split(Oct S, uint32_t lb, uint32
     }
 }
 
-__global__ void __launch_bounds__(kBlock) k_oct_descend(Oct S) {   // push_at_octant, octree.rs:77-104, for every arrival of the level
-    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
-    const uint32_t m = t < S.n ? S.cur[t] : kNone;
-    bool go = false; uint32_t child = 0u;
-    if (m != kNone) {
-        if (S.first[m] == t) { S.own[t] = m; S.cur[t] = kNone; }                    // the first arrival found an empty leaf (octree.rs:77-78)
-        else {
-            // The reference tests the newcomer's box against each child box (aabb.rs:49-60).  It touches the node's own box (checked at the root, true by
-            // induction below), and the children are that box cut at its mid planes, so per axis "touches the lower half" is exactly !(lo > mid) and
-            // "touches the upper half" !(hi < mid): 6 comparisons, the count of touched children is the product (octree.cpp has the same form).
-            const double* tb = &S.tbox[6 * (size_t)t]; const double* nb = &S.nbox[6 * (size_t)m];
-            bool l[3], h[3];
-            for (int a = 0; a < 3; a++) { const double mid = nb[a] + (nb[3 + a] - nb[a]) / 2.0; l[a] = !(tb[a] > mid); h[a] = !(tb[3 + a] < mid); }
-            const int n_touch = ((int)l[0] + (int)h[0]) * ((int)l[1] + (int)h[1]) * ((int)l[2] + (int)h[2]);
-            if (n_touch == 1) { child = S.child_base[m] + c_child_of[((uint32_t)h[0] << 2) | ((uint32_t)h[1] << 1) | (uint32_t)h[2]]; S.cur[t] = child; go = true; }
-            else { S.own[t] = m; S.cur[t] = kNone; }                                // octree.rs:90-92,102-104
+__global__ void __launch_bounds__(kOctBlock) k_oct_descend(Oct S, uint32_t next_begin, uint32_t blocks_before) {   // push_at_octant, octree.rs:77-104, for every arrival of the level
+    __shared__ uint32_t s_min[kLdsNodes], s_cnt[kLdsNodes], s_total;
+    if (threadIdx.x == 0) s_total = 0u;
+    LdsMerge M; M.begin(s_min, s_cnt, next_begin, 8u * (S.ctr[0] - blocks_before));   // the level below: the children k_oct_split has just created
+    const uint32_t n_round = (S.n + 63u) & ~63u;
+    uint32_t n_go = 0;
+    for (uint32_t t = blockIdx.x * kOctBlock + threadIdx.x; t < n_round; t += gridDim.x * kOctBlock) {
+        const uint32_t m = t < S.n ? S.cur[t] : kNone;
+        bool go = false; uint32_t child = next_begin;
+        if (m != kNone) {
+            if (S.first[m] == t) { S.own[t] = m; S.cur[t] = kNone; }                    // the first arrival found an empty leaf (octree.rs:77-78)
+            else {
+                // The reference tests the newcomer's box against each child box (aabb.rs:49-60).  It touches the node's own box (checked at the root, true by
+                // induction below), and the children are that box cut at its mid planes, so per axis "touches the lower half" is exactly !(lo > mid) and
+                // "touches the upper half" !(hi < mid): 6 comparisons, the count of touched children is the product (octree.cpp has the same form).
+                const double* tb = &S.tbox[6 * (size_t)t]; const double* nb = &S.nbox[6 * (size_t)m];
+                bool l[3], h[3];
+                for (int a = 0; a < 3; a++) { const double mid = nb[a] + (nb[3 + a] - nb[a]) / 2.0; l[a] = !(tb[a] > mid); h[a] = !(tb[3 + a] < mid); }
+                const int n_touch = ((int)l[0] + (int)h[0]) * ((int)l[1] + (int)h[1]) * ((int)l[2] + (int)h[2]);
+                if (n_touch == 1) { child = S.child_base[m] + c_child_of[((uint32_t)h[0] << 2) | ((uint32_t)h[1] << 1) | (uint32_t)h[2]]; S.cur[t] = child; go = true; }
+                else { S.own[t] = m; S.cur[t] = kNone; }                                // octree.rs:90-92,102-104
+            }
         }
+        M.add(S.first, S.cnt, child, t, go);
+        n_go += go ? 1u : 0u;
     }
-    arrive(S.first, S.cnt, child, t, go);
-    count_wave(&S.ctr[1], go);
+    M.flush(S.first, S.cnt);
+    count_block(&S.ctr[1], &s_total, n_go);
 }
 
 // ---- temporary ids -> the reference's ids
@@ -243,7 +284,7 @@ __global__ void __launch_bounds__(kBlock) k_idx_items(Idx X) {   // position in 
     const uint32_t F = X.skey[i];
     X.perm_a[i] = i - X.own_off[F];
     const double* tb = &X.tbox[6 * (size_t)X.own_idx[i]];
-    for (int a = 0; a < 3; a++) { double c = (tb[a] + tb[3 + a]) * 0.5; if (c != c) c = 0.0; X.cen_a[3 * (size_t)i + a] = c; }
+    for (int a = 0; a < 3; a++) { double c = (tb[a] + tb[3 + a]) * 0.5; if (c != c) c = 0.0; X.cen_a[(size_t)a * X.n_in + i] = c; }
 }
 
 // One level of the median splits (clusters.cpp: split).  The recursion's SHAPE depends on the list length only: a range of `len` items with leaf
@@ -265,28 +306,66 @@ __device__ __forceinline__ bool walk_to_range(uint32_t n, uint32_t p, uint32_t d
         --steps;
     }
 }
-__global__ void __launch_bounds__(kBlock) k_idx_split(Idx X, uint32_t depth, int flip) {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= X.n_in) return;
-    const uint32_t* ps = flip ? X.perm_b : X.perm_a; uint32_t* pd = flip ? X.perm_a : X.perm_b;
-    const double* cs = flip ? X.cen_b : X.cen_a; double* cd = flip ? X.cen_a : X.cen_b;
-    const uint32_t F = X.skey[i], b0 = X.own_off[F], n = X.own_off[F + 1] - b0;
-    uint32_t b, e, dst = i;
-    const uint32_t pi = ps[i];
-    const double ci[3] = {cs[3 * (size_t)i], cs[3 * (size_t)i + 1], cs[3 * (size_t)i + 2]};
-    if (n > kClusterTris && walk_to_range(n, i - b0, depth, b, e)) {
-        const uint32_t gb = b0 + b, ge = b0 + e;
-        double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
-        for (uint32_t j = gb; j < ge; j++)
-            for (int a = 0; a < 3; a++) { const double c = cs[3 * (size_t)j + a]; lo[a] = c < lo[a] ? c : lo[a]; hi[a] = hi[a] < c ? c : hi[a]; }
-        int axis = 0;
-        for (int a = 1; a < 3; a++) if (hi[a] - lo[a] > hi[axis] - lo[axis]) axis = a;
-        const double c0 = ci[axis];
-        uint32_t r = 0;
-        for (uint32_t j = gb; j < ge; j++) { const double cj = cs[3 * (size_t)j + axis]; const uint32_t pj = ps[j]; r += (cj < c0 || (cj == c0 && pj < pi)) ? 1u : 0u; }
-        dst = gb + r;
+// A wave's 64 consecutive entries belong to one range (long lists) or a few (short ones); the wave handles its distinct ranges one after the other,
+// all 64 lanes working on the range in hand.  Bounds: the lanes stride over the range's entries and reduce (min and max are exact: any order gives the
+// same bits).  Ranks: the range is taken in tiles of 64 entries, one per lane (key on the chosen axis, list position; the next tile's loads are issued
+// before the current tile is compared), and every lane counts the tile's entries that sort before its own, lane q's entry being broadcast through
+// scalar registers (v_readlane): no memory access inside the comparison loop (through LDS the loop waited ~100 cycles per entry: 1.4 ms for the root).
+// The first form of this kernel let every lane walk its own range through the vector memory path: 3.4 ms for the 1 M soup's 10 961-triangle root
+// list, 7.3 ms for all splits; a wave-uniform loop over scalar loads is latency-bound the same way (one s_load per entry, waited for at once).
+// Centroids are stored axis by axis (cen[a * n_in + entry]): a tile's keys are one coalesced load.
+__device__ __forceinline__ double wave_min_f64(double v) { for (int o = 32; o > 0; o >>= 1) { const double w = __shfl_xor(v, o); v = w < v ? w : v; } return v; }
+__device__ __forceinline__ double wave_max_f64(double v) { for (int o = 32; o > 0; o >>= 1) { const double w = __shfl_xor(v, o); v = v < w ? w : v; } return v; }
+__global__ void __launch_bounds__(kBlock) k_idx_split(Idx X, const uint32_t* __restrict__ ps, const double* __restrict__ cs, uint32_t* __restrict__ pd, double* __restrict__ cd, uint32_t depth) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x, lane = threadIdx.x & 63u;
+    const size_t N = X.n_in;
+    const bool valid = i < X.n_in;
+    uint32_t b = 0, e = 0, gb = 0, ge = 0, dst = i, pi = 0;
+    double ci[3] = {0.0, 0.0, 0.0};
+    bool pending = false;
+    if (valid) {
+        const uint32_t F = X.skey[i], b0 = X.own_off[F], n = X.own_off[F + 1] - b0;
+        pi = ps[i];
+        for (int a = 0; a < 3; a++) ci[a] = cs[a * N + i];
+        pending = n > kClusterTris && walk_to_range(n, i - b0, depth, b, e);
+        gb = b0 + b; ge = b0 + e;
     }
-    pd[dst] = pi; cd[3 * (size_t)dst] = ci[0]; cd[3 * (size_t)dst + 1] = ci[1]; cd[3 * (size_t)dst + 2] = ci[2];
+    for (;;) {
+        const unsigned long long pm = __ballot(pending);
+        if (!pm) break;
+        const int leader = __ffsll((long long)pm) - 1;
+        const uint32_t ugb = (uint32_t)__builtin_amdgcn_readlane((int)gb, leader), uge = (uint32_t)__builtin_amdgcn_readlane((int)ge, leader);
+        const bool mine = pending && gb == ugb;
+        // ---- centroid bounds of the range -> the widest axis (clusters.cpp: split)
+        double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+#pragma unroll 8
+        for (uint32_t j = ugb + lane; j < uge; j += 64u)
+            for (int a = 0; a < 3; a++) { const double c = cs[a * N + j]; lo[a] = c < lo[a] ? c : lo[a]; hi[a] = hi[a] < c ? c : hi[a]; }
+        int axis = 0;
+        double best = 0.0;
+        for (int a = 0; a < 3; a++) { const double l = wave_min_f64(lo[a]), h = wave_max_f64(hi[a]), ext = h - l; if (a == 0 || ext > best) { best = ext; axis = a; } }
+        const double c0 = axis == 0 ? ci[0] : axis == 1 ? ci[1] : ci[2];
+        // ---- rank of every entry of the range by (centroid on that axis, list position)
+        const double* keys = cs + (size_t)axis * N;
+        uint32_t r = 0;
+        uint32_t jn = ugb + lane;
+        const double kInfKey = __builtin_huge_val();                     // a tile's unused lanes: (+inf, 0xFFFFFFFF) sorts before nothing
+        double nk = jn < uge ? keys[jn] : kInfKey; uint32_t np = jn < uge ? ps[jn] : kNone;
+        for (uint32_t tile = ugb; tile < uge; tile += 64u) {
+            const double k = nk; const uint32_t p = np;
+            jn = tile + 64u + lane;
+            nk = jn < uge ? keys[jn] : kInfKey; np = jn < uge ? ps[jn] : kNone;   // (the next tile's loads are in flight while this one is compared)
+            const int klo = __double2loint(k), khi = __double2hiint(k);
+#pragma unroll
+            for (int q = 0; q < 64; q++) {                                // lane q's entry, broadcast through scalar registers: no memory in the loop
+                const double cj = __hiloint2double(__builtin_amdgcn_readlane(khi, q), __builtin_amdgcn_readlane(klo, q));
+                const uint32_t pj = (uint32_t)__builtin_amdgcn_readlane((int)p, q);
+                r += (cj < c0 || (cj == c0 && pj < pi)) ? 1u : 0u;
+            }
+        }
+        if (mine) { dst = ugb + r; pending = false; }
+    }
+    if (valid) { pd[dst] = pi; cd[dst] = ci[0]; cd[N + dst] = ci[1]; cd[2 * N + dst] = ci[2]; }
 }
 
 // After the splits: clusters are the runs of 8 list positions; inside a cluster the triangles keep list order (clusters.cpp: std::sort of the cluster).
@@ -493,22 +572,50 @@ struct DevArena {
 };
 struct DevFree { void* p = nullptr; ~DevFree() { if (p) (void)hipFree(p); } };
 
-// ---- pinned staging ring
+// ---- pinned staging: one ring of page-locked chunks per device, shared by every upload and every pageable-framebuffer download of the process.
+// A slot's event says when the DMA that last used it has finished; a slot is waited for right before it is reused, never at the end of a call.
 struct StagingRing {
-    static constexpr int kSlots = 4; static constexpr size_t kSlotBytes = (size_t)8 << 20;
-    std::mutex mu; char* mem = nullptr; hipEvent_t ev[kSlots] = {}; bool ready = false;
+    static constexpr int kSlots = 8; static constexpr size_t kSlotBytes = (size_t)4 << 20;
+    char* mem = nullptr; hipEvent_t ev[kSlots] = {}; bool busy[kSlots] = {}; size_t next = 0; hipStream_t stream = nullptr;
     void ensure() {
-        if (ready) return;
+        if (mem) return;
         HB_TRY(hipHostMalloc((void**)&mem, kSlots * kSlotBytes, hipHostMallocDefault));
         for (auto& e : ev) HB_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        ready = true;
+        HB_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));   // the device's set-up stream (creating one costs ~3 ms: done once, by the warm-up thread when it runs)
     }
+    int acquire() {                                                     // next slot, free to be written
+        const int s = (int)(next++ % kSlots);
+        if (busy[s]) { HB_TRY(hipEventSynchronize(ev[s])); busy[s] = false; }
+        return s;
+    }
+    void release(int s, hipStream_t st) { HB_TRY(hipEventRecord(ev[s], st)); busy[s] = true; }
 };
-StagingRing g_ring;
+constexpr int kMaxDevices = 64;
+std::mutex g_ring_mu;
+StagingRing g_rings[kMaxDevices];
+StagingRing& ring_of_current_device() {                                 // (caller holds g_ring_mu)
+    int dev = 0;
+    HB_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) throw Error{RRT_ERR_INVALID_ARG, "device index beyond the staging table"};
+    g_rings[dev].ensure();
+    return g_rings[dev];
+}
+// parallel memcpy on a few short-lived workers (copies out of the ring on the frame path: thread start-up is ~20 us against megabytes)
+void copy_bytes(char* dst, const char* src, size_t len) {
+    const unsigned workers = std::max(1u, std::min(host_threads(), 4u));
+    if (workers > 1 && len >= ((size_t)2 << 20)) {
+        std::vector<std::thread> th;
+        for (unsigned w = 1; w < workers; w++) th.emplace_back([=] { const size_t b = len * w / workers, e = len * (w + 1) / workers; std::memcpy(dst + b, src + b, e - b); });
+        std::memcpy(dst, src, len / workers);
+        for (auto& t : th) t.join();
+    } else std::memcpy(dst, src, len);
+}
 
 }  // namespace
 
-void staged_upload_warm() { try { std::lock_guard<std::mutex> lk(g_ring.mu); g_ring.ensure(); } catch (...) { (void)hipGetLastError(); } }
+void staged_upload_warm() { try { std::lock_guard<std::mutex> lk(g_ring_mu); (void)ring_of_current_device(); } catch (...) { (void)hipGetLastError(); } }
+
+void* setup_stream() { std::lock_guard<std::mutex> lk(g_ring_mu); return ring_of_current_device().stream; }
 
 void staged_upload(void* dst, const void* src, size_t bytes, void* stream_) {
     if (!bytes) return;
@@ -519,32 +626,76 @@ void staged_upload(void* dst, const void* src, size_t bytes, void* stream_) {
         return;
     }
     (void)hipGetLastError();
-    std::lock_guard<std::mutex> lk(g_ring.mu);
-    g_ring.ensure();
-    const size_t S = StagingRing::kSlotBytes;
-    const size_t n_chunks = (bytes + S - 1) / S;
-    const unsigned workers = std::max(1u, std::min(host_threads(), 8u));
+    std::lock_guard<std::mutex> lk(g_ring_mu);
+    StagingRing& R = ring_of_current_device();
+    const size_t S = StagingRing::kSlotBytes, n_chunks = (bytes + S - 1) / S;
+    // One worker per ring slot, each an independent pipeline: wait for the slot's last DMA, fill the slot from `src`, enqueue its DMA, take the next
+    // chunk -- so the copies into page-locked memory (the slow part: one core moves ~10 GB/s) run on several cores while the DMA engine drains
+    // the finished slots.  Chunks land at disjoint destinations: their order on the stream does not matter.
+    const unsigned workers = (unsigned)std::min<size_t>(std::min<size_t>(StagingRing::kSlots, n_chunks), host_threads());
+    int dev = 0;
+    HB_TRY(hipGetDevice(&dev));
+    std::atomic<size_t> next_chunk{0};
+    std::vector<int> err(workers, 0);
+    auto run = [&](unsigned w) {
+        if (w && hipSetDevice(dev) != hipSuccess) { err[w] = (int)hipGetLastError(); return; }   // (HIP's current device is per thread)
+        char* stage = R.mem + (size_t)w * S;
+        for (size_t c; (c = next_chunk.fetch_add(1)) < n_chunks;) {
+            const size_t off = c * S, len = std::min(S, bytes - off);
+            hipError_t e = hipSuccess;
+            if (R.busy[w]) { e = hipEventSynchronize(R.ev[w]); R.busy[w] = false; }
+            if (e == hipSuccess) { std::memcpy(stage, static_cast<const char*>(src) + off, len); e = hipMemcpyAsync(static_cast<char*>(dst) + off, stage, len, hipMemcpyHostToDevice, stream); }
+            if (e == hipSuccess) { e = hipEventRecord(R.ev[w], stream); R.busy[w] = true; }
+            if (e != hipSuccess) { err[w] = (int)e; return; }
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned w = 1; w < workers; w++) th.emplace_back(run, w);
+    run(0);
+    for (auto& t : th) t.join();
+    for (int e : err) if (e) throw HipBuildFail{e, "staged_upload (pinned-staging host-to-device copy)"};
+    // src has been read completely: it may be freed.  dst is complete once `stream` has drained; the slots guard themselves (busy + event).
+}
+
+// Device -> pageable host memory through the ring: chunk DMAs run ahead while the finished chunks are copied out (a pageable hipMemcpy stages through
+// the runtime's own bounce buffers serially; a frame-sized pinned buffer of the caller's own costs milliseconds to allocate -- more than the
+// reference's one frame takes to trace).  Blocking: dst is complete on return.  Everything enqueued on `stream` before the call is waited for.
+void staged_download(void* dst, const void* src_dev, size_t bytes, void* stream_) {
+    if (!bytes) return;
+    hipStream_t stream = (hipStream_t)stream_;
+    std::lock_guard<std::mutex> lk(g_ring_mu);
+    StagingRing& R = ring_of_current_device();
+    size_t chunk = (bytes / 8 + 0xFFFFF) & ~(size_t)0xFFFFF;              // about 8 chunks per frame, whole MiB, at most a slot
+    chunk = std::min(std::max(chunk, (size_t)1 << 20), StagingRing::kSlotBytes);
+    const size_t n_chunks = (bytes + chunk - 1) / chunk;
+    int slot_of[StagingRing::kSlots];
+    size_t issued = 0;
+    auto issue = [&](size_t c) {
+        const int slot = R.acquire();
+        const size_t off = c * chunk, len = std::min(chunk, bytes - off);
+        HB_TRY(hipMemcpyAsync(R.mem + (size_t)slot * StagingRing::kSlotBytes, static_cast<const char*>(src_dev) + off, len, hipMemcpyDeviceToHost, stream));
+        R.release(slot, stream);
+        slot_of[c % StagingRing::kSlots] = slot;
+    };
+    for (; issued < n_chunks && issued < (size_t)StagingRing::kSlots; issued++) issue(issued);
     for (size_t c = 0; c < n_chunks; c++) {
-        const int slot = (int)(c % StagingRing::kSlots);
-        if (c >= (size_t)StagingRing::kSlots) HB_TRY(hipEventSynchronize(g_ring.ev[slot]));          // the DMA that last read this slot has finished
-        const size_t off = c * S, len = std::min(S, bytes - off);
-        char* stage = g_ring.mem + (size_t)slot * S;
-        const char* from = static_cast<const char*>(src) + off;
-        if (workers > 1 && len >= ((size_t)1 << 20)) {
-            std::vector<std::thread> th;
-            for (unsigned w = 1; w < workers; w++) th.emplace_back([=] { const size_t b = len * w / workers, e = len * (w + 1) / workers; std::memcpy(stage + b, from + b, e - b); });
-            std::memcpy(stage, from, len / workers);
-            for (auto& t : th) t.join();
-        } else std::memcpy(stage, from, len);
-        HB_TRY(hipMemcpyAsync(static_cast<char*>(dst) + off, stage, len, hipMemcpyHostToDevice, stream));
-        HB_TRY(hipEventRecord(g_ring.ev[slot], stream));
+        const int slot = slot_of[c % StagingRing::kSlots];
+        HB_TRY(hipEventSynchronize(R.ev[slot])); R.busy[slot] = false;
+        const size_t off = c * chunk, len = std::min(chunk, bytes - off);
+        copy_bytes(static_cast<char*>(dst) + off, R.mem + (size_t)slot * StagingRing::kSlotBytes, len);
+        if (issued < n_chunks) issue(issued++);
     }
-    // src has been read completely; the ring's slots are protected by their events for the next caller (same lock, events waited before reuse)
-    for (int s = 0; s < StagingRing::kSlots && (size_t)s < n_chunks; s++) HB_TRY(hipEventSynchronize(g_ring.ev[s]));
 }
 
 void gpu_build_scene(const Triangle* tris, uint32_t n, const Box& root, bool enable_cull, const double origin[3], void* stream_, GpuScene& out) {
     hipStream_t st = (hipStream_t)stream_;
+    const bool trace = std::getenv("RRT_SETUP_TRACE") != nullptr;          // developer: host wall time of every stage (synchronising: not the production timing)
+    auto lap = [&, last = std::chrono::steady_clock::now()](const char* what) mutable {
+        if (!trace) return;
+        (void)hipStreamSynchronize(st);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[gpu set-up] %-34s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count()); last = now;
+    };
     hipEvent_t evs[4] = {};
     struct EvGuard { hipEvent_t* e; ~EvGuard() { for (int i = 0; i < 4; i++) if (e[i]) (void)hipEventDestroy(e[i]); } } evg{evs};
     for (auto& e : evs) HB_TRY(hipEventCreate(&e));
@@ -562,12 +713,15 @@ void gpu_build_scene(const Triangle* tris, uint32_t n, const Box& root, bool ena
     DevFree t1;
     DevArena A1;
     A1.cap = (size_t)n * (sizeof(Triangle) + 48 + 3 * 4 + 4 /*rank*/ + 4 * 4 /*key,val in/out*/) + cap * (48 + 4 * 4) + (cap / 8 + 1) * 8 + prim_bytes + (64 << 10);
+    lap("events, rocPRIM size queries");
     HB_TRY(hipMalloc(&t1.p, A1.cap)); A1.base = static_cast<char*>(t1.p);
+    lap("hipMalloc temporaries 1");
 
     HB_TRY(hipEventRecord(evs[0], st));
     Triangle* d_tris = A1.take<Triangle>(n);
     staged_upload(d_tris, tris, sizeof(Triangle) * (size_t)n, st);
     HB_TRY(hipEventRecord(evs[1], st));
+    lap("triangle upload (pinned staging)");
 
     Oct S{};
     S.tris = d_tris; S.n = n;
@@ -583,19 +737,21 @@ void gpu_build_scene(const Triangle* tris, uint32_t n, const Box& root, bool ena
     uint32_t* h_ctr = nullptr;                                         // pinned read-back words
     HB_TRY(hipHostMalloc((void**)&h_ctr, 64 * sizeof(uint32_t), hipHostMallocDefault));
     struct HostFree { void* p; ~HostFree() { if (p) (void)hipHostFree(p); } } hf{h_ctr};
+    lap("hipHostMalloc read-back words");
     auto read_words = [&](const uint32_t* dev, int count) { HB_TRY(hipMemcpyAsync(h_ctr, dev, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, st)); HB_TRY(hipStreamSynchronize(st)); };
 
     // ---- level loop (octree.rs:54-108 for every triangle at once)
     hipLaunchKernelGGL(k_set_root, dim3(1), dim3(1), 0, st, S);
-    if (n) hipLaunchKernelGGL(k_oct_init, dim3(grid_for(n)), dim3(kBlock), 0, st, S);
+    const unsigned oct_grid = std::max(1u, std::min(kOctMaxGrid, (unsigned)((n + kOctBlock - 1) / kOctBlock)));
+    if (n) hipLaunchKernelGGL(k_oct_init, dim3(oct_grid), dim3(kOctBlock), 0, st, S);
     std::vector<uint32_t> level_begin{0u};
     uint32_t n_nodes = 1, lb = 0, le = 1, n_blocks = 0;
     read_words(S.ctr, 2);
     uint32_t active = h_ctr[1];
     while (n && active) {
-        hipLaunchKernelGGL(k_oct_second, dim3(grid_for(n)), dim3(kBlock), 0, st, S);
+        hipLaunchKernelGGL(k_oct_second, dim3(oct_grid), dim3(kOctBlock), 0, st, S, lb, le);
         hipLaunchKernelGGL(k_oct_split, dim3(grid_for(le - lb)), dim3(kBlock), 0, st, S, lb, le);
-        hipLaunchKernelGGL(k_oct_descend, dim3(grid_for(n)), dim3(kBlock), 0, st, S);
+        hipLaunchKernelGGL(k_oct_descend, dim3(oct_grid), dim3(kOctBlock), 0, st, S, le, n_blocks);
         read_words(S.ctr, 2);
         const uint32_t blocks_now = h_ctr[0]; active = h_ctr[1];
         if (blocks_now == n_blocks) break;                             // no node of this level subdivided: it was the last one
@@ -606,6 +762,7 @@ void gpu_build_scene(const Triangle* tris, uint32_t n, const Box& root, bool ena
             throw Error{RRT_ERR_DEPTH, "octree depth exceeds RRT_MAX_OCTREE_DEPTH (" + std::to_string(RRT_MAX_OCTREE_DEPTH) + "): coincident triangles? (octree.rs:79-92)"};
     }
     HB_TRY(hipGetLastError());
+    lap("octree level loop");
     level_begin.push_back(n_nodes);                                     // level L = temporary ids [level_begin[L], level_begin[L + 1])
     out.n_nodes = n_nodes; out.max_depth = (uint32_t)level_begin.size() - 1;
 
@@ -615,6 +772,7 @@ void gpu_build_scene(const Triangle* tris, uint32_t n, const Box& root, bool ena
     DevArena A2;
     A2.cap = oct_bytes + (size_t)n_nodes * (4 /*tmp2final*/ + 4 /*newblock*/ + 6 * 4 /*a_*, bases*/ + 48 /*nb*/) + (size_t)(n_nodes + 1) * 4 * 4 + (size_t)n * (2 * 4 + 2 * 24) + (64 << 10);
     HB_TRY(hipMalloc(&t2.p, A2.cap)); A2.base = static_cast<char*>(t2.p);
+    lap("hipMalloc temporaries 2");
     Remap R{};
     R.n_nodes = n_nodes; R.n_blocks = n_blocks; R.n = n;
     R.second = S.second; R.cnt = S.cnt; R.child_base = S.child_base; R.block_parent = S.block_parent; R.rank = rank; R.own = S.own; R.nbox = S.nbox;
@@ -644,6 +802,7 @@ void gpu_build_scene(const Triangle* tris, uint32_t n, const Box& root, bool ena
     const uint32_t n_in = h_ctr[0];
     out.n_in_tree = n_in;
     HB_TRY(hipEventRecord(evs[2], st));
+    lap("remap, own-list sort");
 
     // ---- index sizes
     double mag = 0;
@@ -672,6 +831,7 @@ void gpu_build_scene(const Triangle* tris, uint32_t n, const Box& root, bool ena
     const uint32_t n_slots_total = n_list_slots + n_leaves, n_cl = n_list_slots / 8;
     out.n_list_slots = n_list_slots; out.n_slots_total = n_slots_total; out.n_sup_records = n_sup; out.n_clusters = n_cl; out.has_groups = has_groups; out.inline_leaves = X.inline_leaves; out.max_own = max_own;
     X.n_list_slots = n_list_slots; X.n_slots_total = n_slots_total;
+    lap("index sizes + scans");
 
     // ---- third allocation: what the trace kernels read (kept) + the octree (kept) in one piece; slot-sized temporaries in a piece of their own
     {
@@ -698,6 +858,7 @@ void gpu_build_scene(const Triangle* tris, uint32_t n, const Box& root, bool ena
     HB_TRY(hipMalloc(&t3.p, A4.cap)); A4.base = static_cast<char*>(t3.p);
     X.slot_tri = out.slot_tri; X.slot_pos = out.slot_pos; X.cluster_node = A4.take<uint32_t>(n_cl + 8); X.cl_lohi = A4.take<float>(6 * (size_t)(n_cl + 8));
     X.supers = out.supers; X.cboxes = out.cboxes; X.tboxes = out.tboxes; X.child_boxes = out.child_boxes; X.nodes = out.nodes; X.geom = out.geom; X.attr = out.attr;
+    lap("hipMalloc scene + temporaries 3, octree copies");
 
     // ---- median splits, level by level: ceil(log2(super-clusters of the longest list)) splits down to super-clusters, 3 more down to clusters
     int flip = 0;
@@ -707,8 +868,12 @@ void gpu_build_scene(const Triangle* tris, uint32_t n, const Box& root, bool ena
             uint32_t parts = (max_own + kSuperTris - 1) / kSuperTris, depth64 = 0;
             while ((1u << depth64) < parts) depth64++;
             const uint32_t passes = depth64 + 3;
-            for (uint32_t d = 0; d < passes; d++) { hipLaunchKernelGGL(k_idx_split, dim3(grid_for(n_in)), dim3(kBlock), 0, st, X, d, flip); flip ^= 1; }
+            for (uint32_t d = 0; d < passes; d++) {
+                hipLaunchKernelGGL(k_idx_split, dim3(grid_for(n_in)), dim3(kBlock), 0, st, X, flip ? X.perm_b : X.perm_a, flip ? X.cen_b : X.cen_a, flip ? X.perm_a : X.perm_b, flip ? X.cen_a : X.cen_b, d);
+                flip ^= 1;
+            }
         }
+        lap("median splits");
         hipLaunchKernelGGL(k_idx_scatter, dim3(grid_for(n_in)), dim3(kBlock), 0, st, X, flip);
     }
     hipLaunchKernelGGL(k_idx_leaf_slots, dim3(grid_for(n_nodes)), dim3(kBlock), 0, st, X);
@@ -726,6 +891,7 @@ void gpu_build_scene(const Triangle* tris, uint32_t n, const Box& root, bool ena
     if (enable_cull && n && out.pad > 0) hipLaunchKernelGGL(k_suspects, dim3(grid_for(n)), dim3(kBlock), 0, st, d_tris, S.own, n, origin[0], origin[1], origin[2], out.pad, d_sus_count, d_sus);
     HB_TRY(hipGetLastError());
     HB_TRY(hipEventRecord(evs[3], st));
+    lap("scatter, records, boxes, sweep, suspects");
     read_words(X.flags, 4);
     out.bounds_plain = h_ctr[2] ? 0u : 1u;
     out.n_suspects = h_ctr[3];
@@ -742,6 +908,9 @@ void gpu_build_scene(const Triangle* tris, uint32_t n, const Box& root, bool ena
     HB_TRY(hipEventElapsedTime(&ms, evs[0], evs[1])); out.ms_upload = ms;
     HB_TRY(hipEventElapsedTime(&ms, evs[1], evs[2])); out.ms_octree = ms;
     HB_TRY(hipEventElapsedTime(&ms, evs[2], evs[3])); out.ms_index = ms;
+    lap("read-backs, suspects");
+    for (DevFree* f : {&t3, &t2, &t1}) { if (f->p) (void)hipFree(f->p); f->p = nullptr; }
+    lap("hipFree temporaries");
 }
 
 }  // namespace rrt

@@ -36,6 +36,11 @@ void gpu_build_scene(const Triangle* tris, uint32_t n_tris, const Box& root, boo
 // Pinned-staging upload of a host buffer (pageable or not) to device memory on `stream`: worker threads fill a ring of page-locked chunks while
 // the DMA engine drains it.  Returns after the last chunk has been ENQUEUED and copied out of `src` (src may be freed; dst is ready after a stream sync).
 void staged_upload(void* dst, const void* src, size_t bytes, void* stream);
-void staged_upload_warm();    // allocates the ring (called from the warm-up thread so that the first upload does not pay for it)
+void staged_upload_warm();    // allocates the current device's ring and set-up stream (called from the warm-up thread so that the first upload does not pay for it)
+// Device memory -> pageable host memory through the same ring, blocking (chunk DMAs run ahead of the copies out of the ring).
+void staged_download(void* dst, const void* src_dev, size_t bytes, void* stream);
+// The current device's shared non-blocking stream (hipStream_t) for set-up work and blocking host-framebuffer renders: creating a stream costs
+// milliseconds, the reference's whole frame takes less.  Owned by the library; never destroyed.
+void* setup_stream();
 
 }  // namespace rrt

@@ -111,3 +111,19 @@ def test_partition_is_balanced_and_complete(rrt):
         owner = rrt.tile_owner_map(w, h, world)
         counts = np.bincount(owner.ravel(), minlength=world)
         assert counts.max() - counts.min() <= 1 and counts.max() == rrt.tiles_per_rank(w, h, world)
+
+
+def test_bench_supervisor_kills_a_hung_child_group():
+    """bench.py's N > 1 supervisor (GPU-free parent): a child group that does not finish is killed as a process group at its timeout, and its last
+    `[bench stage]` line and stderr tail are what gather_paths.<path>.error reports; a group that finishes hands back its one JSON line."""
+    import importlib.util, sys, time
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    hang = "import sys, time; print('[bench stage] library gather: sleeping', file=sys.stderr, flush=True); time.sleep(600)"
+    t0 = time.time()
+    line, rc, tail, timed_out = bench.run_group([sys.executable, "-c", hang], dict(os.environ), 2.0)
+    assert timed_out and line is None and rc != 0 and time.time() - t0 < 30 and any("[bench stage] library gather: sleeping" in t for t in tail)
+    ok = "print('{\"metric\": \"m\", \"value\": 1}')"
+    line, rc, tail, timed_out = bench.run_group([sys.executable, "-c", ok], dict(os.environ), 30.0)
+    assert not timed_out and rc == 0 and line == '{"metric": "m", "value": 1}'
+    assert bench._strip_opt(["--gpus", "8", "--gather", "lib", "--steps", "5", "--gather=torch"], "--gather") == ["--gpus", "8", "--steps", "5"]

@@ -461,11 +461,19 @@ def test_bench_multi_gpu_choreography_single_rank():
     piped = run({"RRT_BENCH_FORCE_DIST": "1"}, "--gather", "torch")
     plain = run({"RRT_BENCH_FORCE_DIST": "1"}, "--gather", "torch", "--pipeline-depth", "0")
     assert single["frame_checksum"] == inlib["frame_checksum"] == piped["frame_checksum"] == plain["frame_checksum"] == both["frame_checksum"]
-    assert set(both["gather_paths"]) == {"torch", "lib"} and both["gather_paths"]["lib"]["same_frame_as_torch_path"] is True
+    assert set(both["gather_paths"]) == {"torch", "lib"} and both["gather_paths"]["lib"]["frame_checksum"] == both["gather_paths"]["torch"]["frame_checksum"] == single["frame_checksum"]
     assert both["gather"] in ("lib", "torch") and both["value"] == max(both["gather_paths"]["lib"]["value"], both["gather_paths"]["torch"]["value"])
     assert single["n_gpus"] == 1 and single["unit"] == "Mrays/s"
     assert inlib["gather"] == "lib" and piped["gather"] == "torch" and inlib["pipeline_fallback"] is False and inlib["gather_ms"] is not None
     assert "frame_ms_host_fb" in single and single["host_fb"]["identical_to_device_frame"] and "setup_ms" in single
+    assert single["first_frame"]["identical_to_steady_frame"] and single["first_frame_ms"] > 0
+    # A library path that never finishes (test hook: the child sleeps before rrt_dist_create): the GPU-free supervisor kills that child group at its
+    # timeout, reports the stage it hung in, prints the torch path's line and exits 0 -- nothing is decided by a process that holds the GPU.
+    hung = run({"RRT_BENCH_FORCE_DIST": "1", "RRT_BENCH_TEST_HANG": "lib"}, "--lib-timeout", "40")
+    err = hung["gather_paths"]["lib"]["error"]
+    assert hung["gather"] == "torch" and hung["frame_checksum"] == single["frame_checksum"] and "timed out" in err and "RRT_BENCH_TEST_HANG" in err, err
+    text = open(os.path.join(root, "bench.py")).read()
+    assert "os._exit" not in text and "watchdog()" not in text
 
 
 @pytest.mark.gpu

@@ -8,5 +8,5 @@ HERE="$(cd "$(dirname "$0")" && pwd)"
 cd "$HERE/../rust-ray-tracer_amd/csrc"
 NAME=$1; EXTRA=$2; RENDER=${3:-render.hip}
 KF=${KFLAGS-$(python3 "$HERE/_kflags.py")}
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math $KF -I. $EXTRA -shared -o ../librrt_hip_$NAME.so api.cpp octree.cpp clusters.cpp obj_loader.cpp image_decode.cpp $RENDER -lz 2>/tmp/build_variant_$NAME.log || { tail -5 /tmp/build_variant_$NAME.log; echo "FAILED librrt_hip_$NAME.so"; exit 1; }
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math $KF -I. $EXTRA -shared -o ../librrt_hip_$NAME.so api.cpp octree.cpp clusters.cpp obj_loader.cpp image_decode.cpp scene_build.hip $RENDER -lz 2>/tmp/build_variant_$NAME.log || { tail -5 /tmp/build_variant_$NAME.log; echo "FAILED librrt_hip_$NAME.so"; exit 1; }
 echo built librrt_hip_$NAME.so
