@@ -95,6 +95,13 @@ typedef struct {
     uint32_t filter_variant;          /* 0 = LANE filter, 1 = BUNDLE filter, 2 = RAY walk (forced, or measured on the first frame of this size) */
     uint32_t origin_plane_triangles;  /* triangles whose plane contains the raytracer's origin to rounding distance: rays from the origin that lie
                                        * in such a plane run with the index filters off (exactness guard); 0 for ordinary scenes */
+    /* The index's exactness band.  filter_pad = absolute padding of every index box (2^-15 of the scene magnitude).  A (ray,
+     * triangle) pair can only be treated differently from the reference-order walk if the ray's direction is within alpha of the triangle's plane AND
+     * its origin within delta of it, alpha = filter_alpha_unit * R / sin(phi), delta = filter_delta_unit * R^2 / sin(phi)^2 (leading term), with
+     * R = |origin - v1| + the longer edge in units of the scene magnitude and phi the angle between the edges: the `unit` values are those of a
+     * right-angled triangle at the scene's magnitude (about 2e-9 and 1e-7 of it).  profiles/r03_band_counts.json: no pair of the five BASELINE frames
+     * that the reference accepts lies inside the band. */
+    double filter_pad, filter_alpha_unit, filter_delta_unit;
 } rrt_stats;
 
 /* ------------------------------------------------------------------ model = SceneData (scenedata.rs:5-13), host side */

@@ -67,7 +67,8 @@ class CModelInfo(C.Structure):
 
 class CStats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("width", C.c_uint32), ("height", C.c_uint32), ("rays_primary", C.c_uint64), ("scene_bytes", C.c_uint64),
-                ("filter_variant", C.c_uint32), ("origin_plane_triangles", C.c_uint32)]
+                ("filter_variant", C.c_uint32), ("origin_plane_triangles", C.c_uint32),
+                ("filter_pad", C.c_double), ("filter_alpha_unit", C.c_double), ("filter_delta_unit", C.c_double)]
 
 
 class CSetupTimes(C.Structure):

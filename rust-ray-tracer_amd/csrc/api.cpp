@@ -648,7 +648,7 @@ int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n
             S.lights[i].v[0] = lights[i].v.x; S.lights[i].v[1] = lights[i].v.y; S.lights[i].v[2] = lights[i].v.z;
         }
 #ifdef RRT_PROFILE
-        { void* pb = nullptr; HIP_TRY(hipMalloc(&pb, 24 * sizeof(unsigned long long))); HIP_TRY(hipMemset(pb, 0, 24 * sizeof(unsigned long long)));
+        { void* pb = nullptr; HIP_TRY(hipMalloc(&pb, 32 * sizeof(unsigned long long))); HIP_TRY(hipMemset(pb, 0, 32 * sizeof(unsigned long long)));
           rt->allocs.push_back(pb); S.prof = static_cast<unsigned long long*>(pb); }
 #endif
         HIP_TRY(hipEventCreate(&rt->ev0)); HIP_TRY(hipEventCreate(&rt->ev1));
@@ -1195,6 +1195,16 @@ int rrt_prof_counters(rrt_raytracer* rt, unsigned long long* out16) {
         return RRT_OK;
     });
 }
+// developer build `make band`: read and clear the four (alpha, delta)-band pair counters (render.hip: band_count)
+int rrt_prof_band_counters(rrt_raytracer* rt, unsigned long long* out4) {
+    return guarded([&]() -> int {
+        DeviceGuard guard(rt->device);
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(out4, rt->scene.prof + 24, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemset(rt->scene.prof + 24, 0, 4 * sizeof(unsigned long long)));
+        return RRT_OK;
+    });
+}
 #endif
 
 int rrt_get_setup_times(const rrt_model* m, const rrt_raytracer* rt, rrt_setup_times* out) {
@@ -1225,6 +1235,12 @@ int rrt_last_stats(const rrt_raytracer* rt_c, rrt_stats* out) {
         }
         if (!rt->launched) rt->stats.filter_variant = (uint32_t)rt->walk;   // (before the first launch: the forced variant, or 0)
         rt->stats.origin_plane_triangles = rt->n_suspects; rt->stats.scene_bytes = rt->scene_bytes;
+        {   // the exactness band of the index (clusters.cpp: find_origin_suspects has the per-pair formulas)
+            const double mag = (double)rt->scene.cull_limit / 4.0, pad = mag / 32768.0, eps = 0x1p-53;
+            rt->stats.filter_pad = rt->scene.cull_enabled ? pad : 0.0;
+            rt->stats.filter_alpha_unit = (rt->scene.cull_enabled && pad > 0) ? 8.0 * 64.0 * eps * mag / pad : 0.0;
+            rt->stats.filter_delta_unit = (rt->scene.cull_enabled && pad > 0) ? 2.0 * (rt->stats.filter_alpha_unit * mag + 64.0 * eps * mag) : 0.0;
+        }
         *out = rt->stats;
         return RRT_OK;
     });

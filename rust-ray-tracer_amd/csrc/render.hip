@@ -371,7 +371,7 @@ __device__ __forceinline__ bool origin_ray_in_suspect_plane(const DevScene& S, V
 
 // ------------------------------------------------------------------------------------------------ developer counters
 #ifdef RRT_PROFILE
-struct Prof { unsigned long long c[16]; unsigned long long t[8]; unsigned long long last; };
+struct Prof { unsigned long long c[16]; unsigned long long t[8]; unsigned long long last; unsigned long long b[4]; double pad; bool secondary; };
 #define PROF_DECL Prof& prof,
 #define PROF_ARG prof,
 // Counters are per WAVE: whichever lane is the first active one at the increment adds to its own copy, and every lane's copies are summed at the end
@@ -391,6 +391,29 @@ __device__ __forceinline__ bool prof_leader() {
 #define PROF_ARG
 #define PROF_ADD(i, x) ((void)0)
 #define PROF_T(i) ((void)0)
+#endif
+// Developer build `make band` (-DRRT_PROFILE -DRRT_BAND_COUNT, run with RRT_FLAG_NO_CULL so that every listed pair is tested): counts the (ray,
+// triangle) pairs that the reference's Moller-Trumbore ACCEPTS and, of those, the pairs inside the (alpha, delta) band of DESIGN.md section 4 --
+// direction within alpha of the triangle's plane AND origin within delta of it -- the only pairs the index's box filters could drop wrongly.
+// b[0]/b[1]: accepted / in-band pairs of SECONDARY rays (origin != the raytracer's origin: shadow and reflection rays, unguarded);
+// b[2]/b[3]: the same for rays from the origin (guarded: clusters.cpp find_origin_suspects).  tools/band_count.py reports them per BASELINE frame.
+#if defined(RRT_PROFILE) && defined(RRT_BAND_COUNT)
+__device__ __noinline__ void band_count(Prof& prof, double v1x, double v1y, double v1z, V3 e1, V3 e2, V3 o, V3 d) {
+    const double eps = 0x1p-53;
+    const V3 s = mk(o.x - v1x, o.y - v1y, o.z - v1z);
+    const V3 n = cross(e1, e2);
+    const double l1 = length(e1), l2 = length(e2), ln = length(n), ls = length(s), ld = length(d);
+    const double R = ls + fmax(l1, l2), sinphi = ln / (l1 * l2);
+    double alpha = 2.0, delta = kInf;
+    if (sinphi > 1e-300) { alpha = 8.0 * 64.0 * eps * R / (prof.pad * sinphi); delta = 2.0 * (alpha * R + 64.0 * eps * R) / sinphi; }
+    const double sin_theta = fabs(dot(d, n)) / (ld * ln), rho = fabs(dot(s, n)) / ln;
+    const bool in_band = (alpha >= 1.0 || sin_theta <= alpha) && rho <= delta;
+    prof.b[prof.secondary ? 0 : 2] += 1ull;
+    if (in_band) prof.b[prof.secondary ? 1 : 3] += 1ull;
+}
+#define MT_UNIFORM(tri, o, d, t) (mt_uniform(tri, o, d, t) && (band_count(prof, tri.v1x, tri.v1y, tri.v1z, mk(tri.e1x, tri.e1y, tri.e1z), mk(tri.e2x, tri.e2y, tri.e2z), o, d), true))
+#else
+#define MT_UNIFORM(tri, o, d, t) mt_uniform(tri, o, d, t)
 #endif
 
 // ------------------------------------------------------------------------------------------------ traversal
@@ -562,7 +585,7 @@ __device__ __forceinline__ void own_cluster_lane(PROF_DECL const RRT_CONSTANT De
             double t;
             const bool ht = (lane_tri >> s) & 1u;
             PROF_ADD(2, 1); PROF_ADD(3, __popcll(__ballot(ht)));
-            if (ht && mt_uniform(tri, o, d, t) && (t < own_t || (t == own_t && tri.pos < own_pos))) { own_t = t; own_slot = cb0 + s; own_pos = tri.pos; }
+            if (ht && MT_UNIFORM(tri, o, d, t) && (t < own_t || (t == own_t && tri.pos < own_pos))) { own_t = t; own_slot = cb0 + s; own_pos = tri.pos; }
             if (!wave_tri) break;
             wave_tri &= wave_tri - 1u;
             tri = nxt; s = s_next;
@@ -623,6 +646,9 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
     }
 #endif
 
+#if defined(RRT_PROFILE) && defined(RRT_BAND_COUNT)
+    prof.secondary = !(o.x == S.origin[0] && o.y == S.origin[1] && o.z == S.origin[2]); prof.pad = (double)S.cull_limit / 131072.0;   // pad = magnitude / 2^15, cull_limit = 4 magnitude
+#endif
     PROF_ADD(6, 1); PROF_ADD(7, __popcll(__ballot(active)));
     PROF_T(5);                                                           // [5] traverse set-up (ray32) + whatever ran since the last stamp outside
     for (;;) {
@@ -719,7 +745,7 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                                 const UTri tri = load_utri(geom + N.leaf_base + (uint32_t)__builtin_popcount((fl >> 9) & ((1u << k) - 1u)));
                                 double tl;
                                 PROF_ADD(2, 1); PROF_ADD(3, __popcll(__ballot(nchild != 0u)));
-                                if (nchild) { if (mt_uniform(tri, o, d, tl)) leaf_hit = 1u << k; else nchild = 0u; }
+                                if (nchild) { if (MT_UNIFORM(tri, o, d, tl)) leaf_hit = 1u << k; else nchild = 0u; }
                             }
                         }
                     } else {
@@ -779,7 +805,7 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                                 double tl;
                                 const bool cand = (vmask >> k) & 1u;
                                 PROF_ADD(2, 1); PROF_ADD(3, __popcll(__ballot(cand)));
-                                if (cand) { if (mt_uniform(tri, o, d, tl)) leaf_hit |= 1u << k; else vmask &= ~(1u << k); }
+                                if (cand) { if (MT_UNIFORM(tri, o, d, tl)) leaf_hit |= 1u << k; else vmask &= ~(1u << k); }
                                 if (!lm) break;
                                 lm &= lm - 1u;
                                 tri = nxt; k = k_next;
@@ -872,7 +898,7 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                                 if (i + 1 < n3) { slot_n = (uint32_t)__builtin_amdgcn_readlane((int)l3a, (int)(i + 1)); nxt = load_utri(geom + slot_n); }   // scalar prefetch
                                 double t;
                                 PROF_ADD(2, 1); PROF_ADD(3, __popcll(__ballot(mine)));
-                                if (mine && mt_uniform(tri, o, d, t) && (t < own_t || (t == own_t && tri.pos < own_pos))) { own_t = t; own_slot = slot; own_pos = tri.pos; }
+                                if (mine && MT_UNIFORM(tri, o, d, t) && (t < own_t || (t == own_t && tri.pos < own_pos))) { own_t = t; own_slot = slot; own_pos = tri.pos; }
                                 tri = nxt; slot = slot_n;
                             }
                         }
@@ -1440,6 +1466,7 @@ __global__ __launch_bounds__(64, kWalk == kWalkBundle ? RRT_WAVES_BUNDLE : kWalk
     PROF_T(4);
     for (int i = 0; i < 16; i++) if (prof.c[i]) atomicAdd(S.prof + i, prof.c[i]);
     if (lane == 0) { for (int i = 0; i < 8; i++) if (prof.t[i]) atomicAdd(S.prof + 16 + i, prof.t[i]); }
+    for (int i = 0; i < 4; i++) if (prof.b[i]) atomicAdd(S.prof + 24 + i, prof.b[i]);        // (per lane: band_count events are per ray)
 #endif
     // Color::mix over the 4 sub-samples of the pixel = 4 consecutive lanes (entities.rs:49-69): u64 sums, truncating /4
     uint32_t r = (c >> 16) & 255u, g = (c >> 8) & 255u, b = c & 255u;
@@ -1481,6 +1508,9 @@ __global__ __launch_bounds__(64) void ray_colour_kernel(const DevScene S, uint32
     Prof prof{}; prof.last = 0;
 #endif
     const uint32_t c = trace_colour<kWalk, true>(PROF_ARG S, stk, ok, o, d);
+#if defined(RRT_PROFILE) && defined(RRT_BAND_COUNT)
+    for (int k = 0; k < 4; k++) if (prof.b[k]) atomicAdd(S.prof + 24 + k, prof.b[k]);
+#endif
     if (ok) colours[i] = c;
 }
 
@@ -1500,6 +1530,9 @@ __global__ __launch_bounds__(64) void intersect_kernel(const DevScene S, uint32_
 #endif
     if constexpr (kWalk == kWalkRay) traverse_ray<true>(PROF_ARG S, stk, ok, false, !origin_ray_in_suspect_plane(S, o, d), o, d, mt, t, slot);
     else traverse<kWalk == kWalkBundle, true>(PROF_ARG S, stk, ok, false, !origin_ray_in_suspect_plane(S, o, d), o, d, mt, t, slot);
+#if defined(RRT_PROFILE) && defined(RRT_BAND_COUNT)
+    for (int k = 0; k < 4; k++) if (prof.b[k]) atomicAdd(S.prof + 24 + k, prof.b[k]);
+#endif
     if (!ok) return;
     if (slot == kNone) { hit[i] = 0; t_out[i] = 0; u_out[i] = 0; v_out[i] = 0; tri_out[i] = kNone; return; }
     double t2, u = 0, v = 0;

@@ -25,7 +25,7 @@ def test_header_symbols_are_exported_and_bound(rrt):
 
 def test_struct_layouts_match_header(rrt):
     assert ctypes.sizeof(rrt.Vec3) == 24 and ctypes.sizeof(rrt.CLight) == 40 and ctypes.sizeof(rrt.CMaterial) == 96
-    assert ctypes.sizeof(rrt.CTexture) == 16 and ctypes.sizeof(rrt.COptions) == 40 and ctypes.sizeof(rrt.CModelInfo) == 32 and ctypes.sizeof(rrt.CStats) == 40
+    assert ctypes.sizeof(rrt.CTexture) == 16 and ctypes.sizeof(rrt.COptions) == 40 and ctypes.sizeof(rrt.CModelInfo) == 32 and ctypes.sizeof(rrt.CStats) == 64
 
 
 def test_strerror_and_build_info(rrt):

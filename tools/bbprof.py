@@ -143,7 +143,9 @@ def build():
 
 
 def run(args):
-    env = dict(os.environ, RRT_LIB=os.path.join(ROOT, "rust-ray-tracer_amd", "librrt_hip_dev.so"), RRT_DEV_HSACO=HSACO, RRT_DEV_BBPROF_OUT=COUNTS)
+    # (RRT_BBPROF_LIB / RRT_BBPROF_HSACO: copies under another name -- *_dev.so and *.hsaco are developer artefacts that .gpurunignore keeps off the GPU box)
+    env = dict(os.environ, RRT_LIB=os.environ.get("RRT_BBPROF_LIB", os.path.join(ROOT, "rust-ray-tracer_amd", "librrt_hip_dev.so")),
+               RRT_DEV_HSACO=os.environ.get("RRT_BBPROF_HSACO", HSACO), RRT_DEV_BBPROF_OUT=COUNTS)
     if os.path.exists(COUNTS): os.remove(COUNTS)
     subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-host-fb", *args], env=env, check=True)
     print("->", COUNTS)
@@ -162,11 +164,16 @@ def report(counts_path=COUNTS, map_path=MAP, out_json=None):
         blocks = kernels[name]["blocks"]
         cnt = [c / n for c in sums[name][:len(blocks)]]
         cls = collections.Counter(); by_line = collections.Counter(); by_op = collections.Counter(); tot = collections.Counter()
+        s_op = collections.Counter(); s_line = collections.Counter(); nop_after = collections.Counter(); prev_op = None
         for b, c in zip(blocks, cnt):
             for op, line in b["ops"]:
                 kind = "VALU" if op.startswith("v_") else "SALU" if op.startswith("s_") and not op.startswith(("s_load", "s_buffer_load", "s_waitcnt", "s_nop")) else \
                        "SMEM" if op.startswith(("s_load", "s_buffer_load")) else "LDS" if op.startswith("ds_") else "VMEM" if op.startswith(("global_", "scratch_", "flat_", "buffer_")) else "other"
                 tot[kind] += c
+                if not op.startswith("v_"):
+                    s_op[op] += c; s_line[line] += c
+                    if op == "s_nop": nop_after[prev_op] += c
+                prev_op = op
                 if kind == "VALU":
                     cls[opclass(op)] += c; by_line[line] += c; by_op[re.sub(r"_e32$|_e64$", "", op)] += c
         src = open(os.path.join(CSRC, "render.hip")).read().split("\n")
@@ -180,7 +187,13 @@ def report(counts_path=COUNTS, map_path=MAP, out_json=None):
         print("  top source lines (VALU):")
         for line, v in by_line.most_common(40):
             print(f"    {100 * v / V:5.1f} %  L{line}: {src[line - 1].strip()[:120] if 0 < line <= len(src) else ''}")
-        result[name] = {"launches": n, "per_launch": dict(tot), "valu_by_class": dict(cls), "valu_by_opcode": dict(by_op.most_common(60)),
+        S = sum(s_op.values()) or 1
+        print(f"  non-VALU instructions by opcode ({S:,.0f} per launch): " + ", ".join(f"{k} {100 * v / S:.1f}%" for k, v in s_op.most_common(30)))
+        print("  s_nop by the instruction before it: " + ", ".join(f"{k} {v:,.0f}" for k, v in nop_after.most_common(10)))
+        print("  top source lines (non-VALU):")
+        for line, v in s_line.most_common(30):
+            print(f"    {100 * v / S:5.1f} %  L{line}: {src[line - 1].strip()[:120] if 0 < line <= len(src) else ''}")
+        result[name] = {"launches": n, "scalar_by_opcode": dict(s_op.most_common(60)), "scalar_by_source_line": {str(k): v for k, v in s_line.most_common(80)}, "per_launch": dict(tot), "valu_by_class": dict(cls), "valu_by_opcode": dict(by_op.most_common(60)),
                         "valu_by_source_line": {str(k): v for k, v in by_line.most_common(80)}, "block_counts": cnt}
     if out_json:
         json.dump(result, open(out_json, "w"), indent=1)
