@@ -338,19 +338,81 @@ __device__ __forceinline__ void slab32_pk(unsigned long long p0, unsigned long l
     tmax = fminf(fminf(X.y, Y.y), Z.y);
 }
 __device__ __forceinline__ unsigned long long sgpr_pair(uint32_t lo, uint32_t hi) { return ((unsigned long long)hi << 32) | lo; }
-__device__ __forceinline__ bool slab32_u(const UBox& b, const Ray32& r) {      // a wave-uniform box held as a UBox (super-cluster records)
-    float tmin, tmax;
-    slab32_pk(sgpr_pair(__builtin_bit_cast(uint32_t, b.cx), __builtin_bit_cast(uint32_t, b.cy)), sgpr_pair(__builtin_bit_cast(uint32_t, b.cz), __builtin_bit_cast(uint32_t, b.hx)),
-              sgpr_pair(__builtin_bit_cast(uint32_t, b.hy), __builtin_bit_cast(uint32_t, b.hz)), r, tmin, tmax);
-    return tmin <= tmax;
+// ---- the box test as ONE asm block (round 3).  Written as one asm statement per instruction (round 2), every dependent pair picked up a compiler
+// s_nop: the hazard recognizer cannot see into inline asm, counts an asm statement as zero wait states and assumes the worst (a partial-register
+// write) of every asm that produces a VGPR -- 3-4 s_nop per box, 0.36 G per 100 k-soup frame, a quarter of the test's instructions, none of them needed
+// by the hardware (full-width VALU results forward with the ordinary interlock).  In one block nothing is inserted.  The temporaries are PINNED
+// (v118..v125): sub-registers of a 64-bit operand cannot be named in an asm template, v_max3/v_min3 need the halves of the packed results.
+#ifndef RRT_NO_FUSED_BOX
+#define RRT_FUSED_BOX 1
+#endif
+#define RRT_BOX_TMP "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125"
+#define RRT_BOX_SLAB                                                                                                                     \
+    "v_pk_fma_f32 v[118:119], %[p0], %[i01], %[n01]\n\t"                                          /* T  = {cx ix + nx, cy iy + ny} */   \
+    "v_pk_fma_f32 v[120:121], %[p1], %[izaz], %[nz0]\n\t"                                         /* TZ = {cz iz + nz, -}        */   \
+    "v_pk_fma_f32 v[122:123], %[p2], %[a01], v[118:119] op_sel:[0,1,1] op_sel_hi:[0,1,1] neg_lo:[1,0,0]\n\t"   /* Y = tcy -/+ hy |iy| */  \
+    "v_pk_fma_f32 v[118:119], %[p1], %[a01], v[118:119] op_sel:[1,0,0] op_sel_hi:[1,0,0] neg_lo:[1,0,0]\n\t"   /* X = tcx -/+ hx |ix| */  \
+    "v_pk_fma_f32 v[120:121], %[p2], %[izaz], v[120:121] op_sel:[1,1,0] op_sel_hi:[1,1,0] neg_lo:[1,0,0]\n\t"  /* Z = tcz -/+ hz |iz| */  \
+    "v_max3_f32 v124, v118, v122, v120 clamp\n\t"                                                 /* near-plane maximum in [0, 1] */   \
+    "v_min3_f32 v125, v119, v123, v121\n\t"                                                       /* far-plane minimum */
+#define RRT_BOX_IN(p0, p1, p2, r) [p0] "s"(p0), [p1] "s"(p1), [p2] "s"(p2), [i01] "v"(r.i01), [n01] "v"(r.n01), [a01] "v"(r.a01), [izaz] "v"(r.izaz), [nz0] "v"(r.nz0)
+// hit mask of one wave-uniform box over the active lanes (== ballot of the per-lane test)
+__device__ __forceinline__ unsigned long long box_mask(unsigned long long p0, unsigned long long p1, unsigned long long p2, const Ray32& r) {
+    unsigned long long m;
+    asm(RRT_BOX_SLAB "v_cmp_le_f32_e64 %[m], v124, v125" : [m] "=s"(m) : RRT_BOX_IN(p0, p1, p2, r) : RRT_BOX_TMP);
+    return m;
 }
 // A burst of boxes: bit i of the lane's accumulator and of the wave's says whether this lane's ray / some lane's ray may hit box i.  The boxes of a
 // burst are tested from the LAST to the first and each result is shifted in from below (acc = 2 acc + hit: one v_addc_co_u32 with the compare's mask
 // as carry-in; the wave's word likewise with s_addc_u32), so box i ends up at bit i whatever the count.
-__device__ __forceinline__ void box_hit_shift(float tmin, float tmax, uint32_t& lane_acc, uint32_t& wave_acc) {
+__device__ __forceinline__ void box_test_shift(unsigned long long p0, unsigned long long p1, unsigned long long p2, const Ray32& r, uint32_t& lane_acc, uint32_t& wave_acc) {
+#ifdef RRT_FUSED_BOX
+    unsigned long long m;
+    asm(RRT_BOX_SLAB
+        "v_cmp_le_f32_e64 %[m], v124, v125\n\t"
+        "v_addc_co_u32_e64 %[la], vcc, %[la], %[la], %[m]"
+        : [la] "+v"(lane_acc), [m] "=&s"(m) : RRT_BOX_IN(p0, p1, p2, r) : "vcc", RRT_BOX_TMP);
+    // (the wave's word in a statement of its own: with the scalar accumulator as an in/out operand of the block above the backend fails with
+    //  "illegal VGPR to SGPR copy"; an SGPR dependency between two asm statements costs no s_nop)
+    asm("s_cmp_lg_u64 %1, 0\n\ts_addc_u32 %0, %0, %0" : "+s"(wave_acc) : "s"(m) : "scc");
+#else
+    float tmin, tmax;
+    slab32_pk(p0, p1, p2, r, tmin, tmax);
     unsigned long long m;
     asm("v_cmp_le_f32_e64 %1, %2, %3\n\tv_addc_co_u32_e64 %0, vcc, %0, %0, %1" : "+v"(lane_acc), "=&s"(m) : "v"(tmin), "v"(tmax) : "vcc");
     asm("s_cmp_lg_u64 %1, 0\n\ts_addc_u32 %0, %0, %0" : "+s"(wave_acc) : "s"(m) : "scc");
+#endif
+}
+// the reach filter's form: the result lands at bit k (children are often absent, so nothing is shifted)
+template <int k> __device__ __forceinline__ void box_test_bit(unsigned long long p0, unsigned long long p1, unsigned long long p2, const Ray32& r, uint32_t& lane_bits, uint32_t& wave_bits) {
+#ifdef RRT_FUSED_BOX
+    unsigned long long m; uint32_t t;
+    asm(RRT_BOX_SLAB
+        "v_cmp_le_f32_e64 %[m], v124, v125\n\t"
+        "v_cndmask_b32_e64 v124, 0, 1, %[m]\n\t"
+        "v_lshl_or_b32 %[lb], v124, %[k], %[lb]\n\t"
+        "s_cmp_lg_u64 %[m], 0\n\t"
+        "s_cselect_b32 %[t], %[bit], 0\n\t"
+        "s_or_b32 %[wb], %[wb], %[t]"
+        : [lb] "+v"(lane_bits), [wb] "+s"(wave_bits), [m] "=&s"(m), [t] "=&s"(t) : RRT_BOX_IN(p0, p1, p2, r), [k] "n"(k), [bit] "n"(1 << k) : "scc", RRT_BOX_TMP);
+#else
+    float tmin, tmax;
+    slab32_pk(p0, p1, p2, r, tmin, tmax);
+    const bool h = tmin <= tmax;
+    lane_bits |= h ? (1u << k) : 0u;
+    wave_bits |= (__builtin_amdgcn_ballot_w64(h) != 0ull) ? (1u << k) : 0u;
+#endif
+}
+__device__ __forceinline__ unsigned long long slab32_u_mask(const UBox& b, const Ray32& r) {      // a wave-uniform box held as a UBox (super-cluster records): hit mask
+    const unsigned long long p0 = sgpr_pair(__builtin_bit_cast(uint32_t, b.cx), __builtin_bit_cast(uint32_t, b.cy)), p1 = sgpr_pair(__builtin_bit_cast(uint32_t, b.cz), __builtin_bit_cast(uint32_t, b.hx)),
+                             p2 = sgpr_pair(__builtin_bit_cast(uint32_t, b.hy), __builtin_bit_cast(uint32_t, b.hz));
+#ifdef RRT_FUSED_BOX
+    return box_mask(p0, p1, p2, r);
+#else
+    float tmin, tmax;
+    slab32_pk(p0, p1, p2, r, tmin, tmax);
+    return __builtin_amdgcn_ballot_w64(tmin <= tmax);
+#endif
 }
 
 // Exactness guard: must the index filter stay off for this ray?  Only rays that start at the raytracer's origin can be
@@ -550,10 +612,8 @@ __device__ __forceinline__ void own_cluster_lane(PROF_DECL const RRT_CONSTANT De
     uint32_t lane_tri = 0, wave_tri = 0;
 #define RRT_TB(v, off)                                                                                                             \
     {                                                                                                                              \
-        float tmin, tmax;                                                                                                          \
-        slab32_pk(sgpr_pair(v[off], v[off + 1]), sgpr_pair(v[off + 2], v[off + 3]), sgpr_pair(v[off + 4], v[off + 5]), r32, tmin, tmax);  \
         PROF_ADD(4, 1);                                                                                                            \
-        box_hit_shift(tmin, tmax, lane_tri, wave_tri);                                                                            \
+        box_test_shift(sgpr_pair(v[off], v[off + 1]), sgpr_pair(v[off + 2], v[off + 3]), sgpr_pair(v[off + 4], v[off + 5]), r32, lane_tri, wave_tri);  \
     }
     {
         // The last box first, results shifted in from below.
@@ -606,6 +666,17 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
     bool done = !active;
     uint32_t cur = 0;        // node this lane has to enter next
     uint32_t sp = 0;         // number of frames on this lane's stack == depth of `cur`
+#ifdef RRT_PREFETCH_NODES
+    // Node records come through dependent SCALAR loads at the start of every visit, and on the soups most of them miss the L2 (140 k nodes x 96 B):
+    // the s_memtime stamps put 42 % of a wave's time between "pick the node" and "its record is here".  A lane knows the node it will enter next as
+    // soon as it has pushed / unwound -- usually many visits before the wave gets to it -- so it touches that record with a VECTOR load then (the
+    // texture-address path idles in this kernel: TA busy 8 %, profiles/r03_mem_lane100k.json); the scalar load later finds the line in the L2.  The
+    // loaded words are kept (fake use at the next prefetch) so that the register is not recycled while the load is in flight.
+    uint32_t pf_tail = 0;
+#if RRT_PREFETCH_NODES > 1
+    uint32_t pf_head = 0;
+#endif
+#endif
     double ret_t = kInf; uint32_t ret_slot = kNone;
     const RRT_CONSTANT DevNode* nodes = (const RRT_CONSTANT DevNode*)own_sgprs(S.nodes);
     const RRT_CONSTANT DevTriGeom* geom = (const RRT_CONSTANT DevTriGeom*)own_sgprs(S.geom);
@@ -684,18 +755,15 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                         const RRT_CONSTANT u32x16* cbx = (const RRT_CONSTANT u32x16*)(child_boxes + (fc - 1u));
 #define RRT_CB(k, v, off)                                                                                                          \
                         if (fl & (1u << k)) {                                                                                      \
-                            bool h;                                                                                                \
                             if constexpr (kBundle) {                                                                               \
                                 UBox B; B.cx = mkf(v[off]); B.cy = mkf(v[off + 1]); B.cz = mkf(v[off + 2]);                     \
                                 B.hx = mkf(v[off + 3]); B.hy = mkf(v[off + 4]); B.hz = mkf(v[off + 5]); B.a = 0; B.b = 0;       \
-                                h = slab32(B, r32);                                                                               \
+                                const bool h = slab32(B, r32);                                                                    \
+                                lane_reach |= h ? (1u << k) : 0u;                                                                  \
+                                reach |= (__builtin_amdgcn_ballot_w64(h) != 0ull) ? (1u << k) : 0u;                                \
                             } else {                                                                                               \
-                                float tmin, tmax;                                                                                  \
-                                slab32_pk(sgpr_pair(v[off], v[off + 1]), sgpr_pair(v[off + 2], v[off + 3]), sgpr_pair(v[off + 4], v[off + 5]), r32, tmin, tmax);  \
-                                h = tmin <= tmax;                                                                                  \
+                                box_test_bit<k>(sgpr_pair(v[off], v[off + 1]), sgpr_pair(v[off + 2], v[off + 3]), sgpr_pair(v[off + 4], v[off + 5]), r32, lane_reach, reach);  \
                             }                                                                                                      \
-                            lane_reach |= h ? (1u << k) : 0u;                                                                      \
-                            reach |= (__builtin_amdgcn_ballot_w64(h) != 0ull) ? (1u << k) : 0u;                                                          \
                         }
                         // (Children are often absent, so the results are OR-ed in at their own bit rather than shifted in as box_hit_shift does: the
                         // zeros to shift in for absent children cost more than the shift saves.  Measured, teapot / 100 k soup / 1 M soup: the packed
@@ -915,8 +983,7 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                 for (uint32_t si = 0; si < sc; ++si) {
                     UBox SN = SP;
                     if (si + 1 < sc) SN = load_ubox(supers + sb + si + 1);                            // scalar prefetch of the next super-cluster
-                    const bool hs = (sc == 1) || slab32_u(SP, r32);
-                    const unsigned long long hs_mask = __builtin_amdgcn_ballot_w64(hs);
+                    const unsigned long long hs_mask = (sc == 1) ? __builtin_amdgcn_ballot_w64(true) : slab32_u_mask(SP, r32);
                     const uint32_t tb = SP.a, tn = SP.b;
                     PROF_ADD(10, 1);
                     if constexpr (kGroups) {
@@ -930,6 +997,11 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                             continue;
                         }
                     }
+#ifdef RRT_SKIP_CBOX_MAX
+                    // A short list in one cluster (90 % of a soup's internal nodes hold <= 8 triangles of their own): its cluster box is one more dependent
+                    // scalar load and test in front of the triangle boxes, which are few -- go to them directly.
+                    if (sc == 1 && tn <= RRT_SKIP_CBOX_MAX) { own_cluster_lane(PROF_ARG tboxes, geom, tb, tn, r32, o, d, own_t, own_slot, own_pos); SP = SN; continue; }
+#endif
                     if (hs_mask != 0ull) {
                         // the (up to) 8 cluster boxes of this super-cluster in bursts of 4; cluster c covers slots tb+8c .. tb+8c+7
                         const RRT_CONSTANT u32x16* cb = (const RRT_CONSTANT u32x16*)(cboxes + (tb >> 3));
@@ -937,10 +1009,8 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                         uint32_t lane_hits = 0, wave_hits = 0;
 #define RRT_CL(v, off)                                                                                                             \
                         {                                                                                                      \
-                            float tmin, tmax;                                                                                  \
-                            slab32_pk(sgpr_pair(v[off], v[off + 1]), sgpr_pair(v[off + 2], v[off + 3]), sgpr_pair(v[off + 4], v[off + 5]), r32, tmin, tmax);  \
                             PROF_ADD(11, 1);                                                                                   \
-                            box_hit_shift(tmin, tmax, lane_hits, wave_hits);                                                  \
+                            box_test_shift(sgpr_pair(v[off], v[off + 1]), sgpr_pair(v[off + 2], v[off + 3]), sgpr_pair(v[off + 4], v[off + 5]), r32, lane_hits, wave_hits);  \
                         }
                         {
                             // (as for the triangle boxes: no mask for the lanes that missed the super-cluster's box)
@@ -1018,6 +1088,14 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                     returning = false;                                   // child returned None -> try the next child
                 }
             }
+#ifdef RRT_PREFETCH_NODES
+            asm volatile("" :: "v"(pf_tail));
+            if (!done) pf_tail = *reinterpret_cast<const volatile uint32_t*>(reinterpret_cast<const char*>((const DevNode*)nodes + cur) + 64);
+#if RRT_PREFETCH_NODES > 1
+            asm volatile("" :: "v"(pf_head));
+            if (!done) pf_head = *reinterpret_cast<const volatile uint32_t*>((const DevNode*)nodes + cur);
+#endif
+#endif
             PROF_T(3);
         }
     }

@@ -164,9 +164,14 @@ def report(counts_path=COUNTS, map_path=MAP, out_json=None):
         blocks = kernels[name]["blocks"]
         cnt = [c / n for c in sums[name][:len(blocks)]]
         cls = collections.Counter(); by_line = collections.Counter(); by_op = collections.Counter(); tot = collections.Counter()
-        s_op = collections.Counter(); s_line = collections.Counter(); nop_after = collections.Counter(); prev_op = None
+        s_op = collections.Counter(); s_line = collections.Counter(); nop_after = collections.Counter(); prev_op = None; inl = collections.Counter()
+        last_line = 0
         for b, c in zip(blocks, cnt):
             for op, line in b["ops"]:
+                # Inlined library code (OCML pow / sqrt / divide expansions) carries no line of render.hip (0, or -file): it is charged to the call site,
+                # i.e. the last render.hip line seen before it in layout order, and counted under "inlined at" so that nothing stays unattributed.
+                if line > 0: last_line = line
+                elif op.startswith("v_"): inl[last_line] += c; line = last_line
                 kind = "VALU" if op.startswith("v_") else "SALU" if op.startswith("s_") and not op.startswith(("s_load", "s_buffer_load", "s_waitcnt", "s_nop")) else \
                        "SMEM" if op.startswith(("s_load", "s_buffer_load")) else "LDS" if op.startswith("ds_") else "VMEM" if op.startswith(("global_", "scratch_", "flat_", "buffer_")) else "other"
                 tot[kind] += c
@@ -187,6 +192,9 @@ def report(counts_path=COUNTS, map_path=MAP, out_json=None):
         print("  top source lines (VALU):")
         for line, v in by_line.most_common(40):
             print(f"    {100 * v / V:5.1f} %  L{line}: {src[line - 1].strip()[:120] if 0 < line <= len(src) else ''}")
+        print(f"  VALU of inlined library code, by the render.hip line it was inlined at ({100 * sum(inl.values()) / V:.1f} % of VALU):")
+        for line, v in inl.most_common(12):
+            print(f"    {100 * v / V:5.1f} %  L{line}: {src[line - 1].strip()[:120] if 0 < line <= len(src) else ''}")
         S = sum(s_op.values()) or 1
         print(f"  non-VALU instructions by opcode ({S:,.0f} per launch): " + ", ".join(f"{k} {100 * v / S:.1f}%" for k, v in s_op.most_common(30)))
         print("  s_nop by the instruction before it: " + ", ".join(f"{k} {v:,.0f}" for k, v in nop_after.most_common(10)))
@@ -194,7 +202,8 @@ def report(counts_path=COUNTS, map_path=MAP, out_json=None):
         for line, v in s_line.most_common(30):
             print(f"    {100 * v / S:5.1f} %  L{line}: {src[line - 1].strip()[:120] if 0 < line <= len(src) else ''}")
         result[name] = {"launches": n, "scalar_by_opcode": dict(s_op.most_common(60)), "scalar_by_source_line": {str(k): v for k, v in s_line.most_common(80)}, "per_launch": dict(tot), "valu_by_class": dict(cls), "valu_by_opcode": dict(by_op.most_common(60)),
-                        "valu_by_source_line": {str(k): v for k, v in by_line.most_common(80)}, "block_counts": cnt}
+                        "valu_by_source_line": {str(k): v for k, v in by_line.most_common(80)},
+                        "valu_inlined_library_code_by_call_line": {str(k): v for k, v in inl.most_common(40)}, "block_counts": cnt}
     if out_json:
         json.dump(result, open(out_json, "w"), indent=1)
     return result
