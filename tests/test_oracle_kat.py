@@ -7,6 +7,7 @@ octree.rs:530-610) and the Aabb::from_triangle boxes (octree.rs:308-319, 410-432
 the cited reference lines.
 """
 import math
+import os
 
 import numpy as np
 
@@ -259,3 +260,36 @@ def test_golden_frames_and_rays(ob, rrt, teapot_oracle):
             assert (t, u, v, tri) == (g["ray_t"][i], g["ray_u"][i], g["ray_v"][i], g["ray_tri"][i])
         assert teapot_oracle.get_ray_colour(g["ray_o"][i], g["ray_d"][i]) == g["ray_col"][i]
     assert int(g["n_nodes"]) == 3265 and int(g["root_own"]) == 1110
+
+
+def test_oracle_silhouette_matches_the_references_only_image(rrt, ob, teapot, teapot_oracle):
+    """The one image the reference holds, example_output.png (README.md:9), shows an OLDER teapot scene (no mirror, untextured teapot) in an 800 x 800
+    minifb window.  It cannot pin arithmetic, but it does pin the camera (main.rs:62-66), the viewport and pixel grid (engine.rs:186-255), the
+    orientation of put_pixel (engine.rs:146-158: y up, no vertical flip, row 0 = top) and the white-miss convention: the oracle's frame of model2.obj
+    at 800 x 800 must cover the same pixels as the screenshot's canvas everywhere outside the projection of the mirror, the one object the old scene
+    lacks.  The fixture is the derived non-white mask (tests/golden/make_example_mask.py), not the image."""
+    m = np.load(os.path.join(GOLDEN, "example_output_mask.npz"))
+    W = H = 800
+    ref = np.unpackbits(m["mask_bits"])[:W * H].reshape(H, W).astype(bool)
+    fb, _ = teapot_oracle.render(W, H)
+    mine = fb != 0xFFFFFF
+    # the mirror: the triangles whose material reflects (model2.obj:25989-25990), projected with the reference's camera model
+    pos, _, _, mat = teapot.triangles()
+    mirror = np.flatnonzero(np.isin(mat, [i for i, mt in enumerate(teapot.materials()) if mt["kr"] > 0]))
+    assert len(mirror) == 2
+    o = np.array([0.0, 2.0, -10.0])
+    yy, xx = np.mgrid[0:H, 0:W]
+    excl = np.zeros((H, W), bool)
+    for t in pos[mirror]:
+        d = t - o
+        px = d[:, 0] / d[:, 2] * W + W / 2; row = H - (d[:, 1] / d[:, 2] * H + H / 2)     # engine.rs:209-236 inverted; put_pixel engine.rs:147-150
+        def side(a, b): return (xx - px[b]) * (row[a] - row[b]) - (px[a] - px[b]) * (yy - row[b])
+        d1, d2, d3 = side(0, 1), side(1, 2), side(2, 0)
+        excl |= ~(((d1 < 0) | (d2 < 0) | (d3 < 0)) & ((d1 > 0) | (d2 > 0) | (d3 > 0)))
+    grown = excl.copy()
+    for _ in range(3):                                                   # 3-pixel margin around the mirror's edge
+        g = grown.copy(); g[1:] |= grown[:-1]; g[:-1] |= grown[1:]; g[:, 1:] |= grown[:, :-1]; g[:, :-1] |= grown[:, 1:]; grown = g
+    keep = ~grown; keep[0] = False                                       # row 0 is never written (engine.rs:152-155)
+    iou = ((ref & mine & keep).sum()) / (((ref | mine) & keep).sum())
+    assert keep.sum() > 0.75 * W * H and iou >= 0.995, f"silhouette IoU outside the mirror {iou:.5f}"
+    assert ref[600:740, :].mean() > 0.9 and not ref[:100, 500:].any()      # the table low in the frame, empty background top right: the frame is not flipped
