@@ -1,7 +1,7 @@
 /*
  * rrt_oracle.c -- CPU restatement (plain C, IEEE f64, no FMA contraction, no fast-math) of the reference
- * renderer's per-pixel hot path.  TEST INFRASTRUCTURE ONLY -- see rrt_oracle.h for the rules and the
- * "parity unpinned" statement.  Build: see oracle/Makefile (gcc -O2 -ffp-contract=off).
+ * renderer's per-pixel hot path.  TEST INFRASTRUCTURE ONLY -- see rrt_oracle.h for the rules and for what
+ * pins it (no runnable reference: "parity unpinned"; octree vectors and the reference's one image do pin it).  Build: see oracle/Makefile (gcc -O2 -ffp-contract=off).
  *
  * Structure deliberately follows the reference (recursive octree walk on an arena of nodes with
  * per-node Vec-like lists), NOT the product's flattened/iterative GPU form, so that the two are

@@ -5,11 +5,18 @@
  * bench.py's cpu_baseline leg may load it, and only as the checker / reported CPU baseline.
  * The product library (librrt_hip.so) neither links nor calls anything in this directory.
  *
- * PARITY STATUS: "parity unpinned by a runnable reference".  The reference is Rust; no Rust toolchain
- * exists in this image or on the GPU box, and the reference ships no live tests or golden images
- * (SURVEY.md section 8c).  The oracle is pinned by (a) the still-valid data vectors in the reference's
- * commented-out octree tests (octree.rs:244-652: child-AABB order/geometry, from_triangle boxes) and
- * (b) hand-derived known-answer tests, see tests/test_oracle_kat.py.
+ * PARITY STATUS: the reference is Rust; no Rust toolchain exists in this image or on the GPU box, so the reference itself cannot be run, and it
+ * ships no live tests or golden vectors: "parity unpinned by a runnable reference".  What the reference DOES hold pins this
+ * oracle as follows (tests/test_oracle_kat.py):
+ *   (a) octree geometry -- the still-valid data vectors of its commented-out octree tests (octree.rs:244-652: child-AABB order and geometry,
+ *       from_triangle boxes);
+ *   (b) pixels -- its one image, example_output.png (README.md:9), a lossless screenshot of an older build's 800 x 800 canvas of the teapot scene:
+ *       the oracle's frame of model2.obj covers the same pixels everywhere outside the mirror that the old scene lacked (IoU 0.9996), canvas row 0 is
+ *       black in the screenshot as put_pixel leaves it here, and on the teapot and the table's front face -- the surfaces both scene versions share --
+ *       86 % of the sampled pixels are bit-equal to the screenshot and 94.5 % within one unit per channel (camera, pixel grid, walk, normal
+ *       interpolation, texel lookup, Phong diffuse + specular powf, shadow rays, Color::mix); the rest sit on grazing-shadow edges where the old
+ *       build evidently differed (fixture: derived mask and crops, tests/golden/make_example_mask.py);
+ *   (c) everything else (mirror recursion, the `break` of the light loop, max_t units, NaN handling, ...) rests on hand-derived known-answer tests.
  *
  * Every function cites the reference file:line it follows (paths relative to the reference root).
  */
