@@ -145,6 +145,14 @@ typedef struct rrt_raytracer rrt_raytracer;
 /* Uploads the scene once to HBM of HIP device `device`.  opt may be NULL. */
 int rrt_raytracer_create(const rrt_model *m, const rrt_light *lights, uint32_t n_lights, rrt_vec3 origin,
                          const rrt_options *opt, int device, rrt_raytracer **out);
+/* The same raytracer straight from the host's own arrays (arguments as rrt_model_from_arrays, then as rrt_raytracer_create): what a host that has
+ * parsed the scene itself -- the Rust host holds SceneData.triangles -- calls when it needs no rrt_model.  The arrays are uploaded from where they lie
+ * and packed into triangle records on the device; the library keeps no host copy of the scene.  Same scene in HBM, same frames; the loaders' copy
+ * (15 ms of a million triangles' 54 ms first frame) is not made.  RRT_FLAG_HOST_SETUP is refused here (RRT_ERR_UNSUPPORTED). */
+int rrt_raytracer_create_from_arrays(uint32_t n_tris, const double *pos, const double *uv, const double *nrm, const uint32_t *mat,
+                                     uint32_t n_mats, const rrt_material *mats, uint32_t n_tex, const rrt_texture *tex, const double *root,
+                                     const rrt_light *lights, uint32_t n_lights, rrt_vec3 origin, const rrt_options *opt, int device,
+                                     rrt_raytracer **out);
 void rrt_raytracer_destroy(rrt_raytracer *rt);
 
 /* Scene::draw_scene (engine.rs:186-255) + Canvas::put_pixel (engine.rs:146-158): fills out_fb[width*height]

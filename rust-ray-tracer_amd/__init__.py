@@ -90,6 +90,8 @@ SYMBOLS = {
     "rrt_decode_image_file": (C.c_int, [C.c_char_p, C.POINTER(_u8p), _u32p, _u32p]),
     "rrt_free": (None, [_P]),
     "rrt_raytracer_create": (C.c_int, [_P, C.POINTER(CLight), C.c_uint32, Vec3, C.POINTER(COptions), C.c_int, C.POINTER(_P)]),
+    "rrt_raytracer_create_from_arrays": (C.c_int, [C.c_uint32, _dp, _dp, _dp, _u32p, C.c_uint32, C.POINTER(CMaterial), C.c_uint32, C.POINTER(CTexture), _dp,
+                                                  C.POINTER(CLight), C.c_uint32, Vec3, C.POINTER(COptions), C.c_int, C.POINTER(_P)]),
     "rrt_raytracer_destroy": (None, [_P]),
     "rrt_render": (C.c_int, [_P, C.c_uint32, C.c_uint32, _u32p]),
     "rrt_host_buffer_register": (C.c_int, [_P, C.c_size_t]),
@@ -202,6 +204,29 @@ DEFAULT_ORIGIN = Vector3d(0.0, 2.0, -10.0)   # src/main.rs:62-66
 DEFAULT_ROOT = (-20.0, 20.0, -20.0, 20.0, -20.0, 20.0)   # src/file_management/utils.rs:145
 
 
+class _Arrays:
+    pass
+
+
+def _marshal_arrays(pos, uv, nrm, mat, materials, textures, root):
+    """ctypes views of a scene held in numpy arrays (no copies of arrays that are already contiguous float64 / uint32 / uint8)."""
+    a = _Arrays()
+    a.pos = np.ascontiguousarray(pos, np.float64).reshape(-1, 9)
+    a.uv = np.ascontiguousarray(uv, np.float64).reshape(-1, 9)
+    a.nrm = np.ascontiguousarray(nrm, np.float64).reshape(-1, 9)
+    a.mat = np.ascontiguousarray(mat, np.uint32)
+    a.n = a.pos.shape[0]
+    a.cm = (CMaterial * max(1, len(materials)))()
+    for i, m in enumerate(materials):
+        a.cm[i] = CMaterial(Vec3(*m["ka"]), Vec3(*m["kd"]), Vec3(*m["ks"]), float(m["ns"]), float(m["kr"]), int(m["tex"]), int(m.get("bump", -1)))
+    a.keep = [np.ascontiguousarray(t, np.uint8) for t in textures]
+    a.ct = (CTexture * max(1, len(a.keep)))()
+    for i, t in enumerate(a.keep):
+        a.ct[i] = CTexture(t.ctypes.data_as(_u8p), t.shape[1], t.shape[0])
+    a.r = (C.c_double * 6)(*root)
+    return a
+
+
 class SceneData:
     """SceneData (scenedata.rs:5-13): triangles in push order + materials + decoded textures + the octree."""
 
@@ -227,21 +252,9 @@ class SceneData:
     @staticmethod
     def from_arrays(pos, uv, nrm, mat, materials: Sequence[dict], textures: Sequence[np.ndarray], root=DEFAULT_ROOT) -> "SceneData":
         """pos/uv/nrm: [n,3,3] float64; mat: [n] uint32; materials: dicts ka,kd,ks,ns,kr,tex,bump; textures: [h,w,3] uint8."""
-        pos = np.ascontiguousarray(pos, np.float64).reshape(-1, 9)
-        uv = np.ascontiguousarray(uv, np.float64).reshape(-1, 9)
-        nrm = np.ascontiguousarray(nrm, np.float64).reshape(-1, 9)
-        mat = np.ascontiguousarray(mat, np.uint32)
-        n = pos.shape[0]
-        cm = (CMaterial * max(1, len(materials)))()
-        for i, m in enumerate(materials):
-            cm[i] = CMaterial(Vec3(*m["ka"]), Vec3(*m["kd"]), Vec3(*m["ks"]), float(m["ns"]), float(m["kr"]), int(m["tex"]), int(m.get("bump", -1)))
-        keep = [np.ascontiguousarray(t, np.uint8) for t in textures]
-        ct = (CTexture * max(1, len(keep)))()
-        for i, t in enumerate(keep):
-            ct[i] = CTexture(t.ctypes.data_as(_u8p), t.shape[1], t.shape[0])
-        r = (C.c_double * 6)(*root)
+        a = _marshal_arrays(pos, uv, nrm, mat, materials, textures, root)
         out = _P()
-        _check(lib().rrt_model_from_arrays(n, _d(pos), _d(uv), _d(nrm), mat.ctypes.data_as(_u32p), len(materials), cm, len(keep), ct, r, C.byref(out)),
+        _check(lib().rrt_model_from_arrays(a.n, _d(a.pos), _d(a.uv), _d(a.nrm), a.mat.ctypes.data_as(_u32p), len(materials), a.cm, len(a.keep), a.ct, a.r, C.byref(out)),
                "rrt_model_from_arrays")
         return SceneData(out.value)
 
@@ -313,6 +326,24 @@ class RayTracer:
         out = _P()
         _check(lib().rrt_raytracer_create(scene_data._h, cl, len(self.lights), origin._c(), C.byref(opt), device, C.byref(out)), "rrt_raytracer_create")
         self._h = out
+
+    @classmethod
+    def from_arrays(cls, pos, uv, nrm, mat, materials: Sequence[dict], textures: Sequence[np.ndarray], lights: Iterable[Light], origin: Vector3d = DEFAULT_ORIGIN,
+                    device: int = 0, root=DEFAULT_ROOT, no_cull: bool = False, box_filter: Optional[str] = None) -> "RayTracer":
+        """rrt_raytracer_create_from_arrays: the raytracer straight from the host's arrays (no SceneData / rrt_model, no host copy of the scene)."""
+        self = cls.__new__(cls)
+        self.scene_data, self.lights, self.origin, self.device = None, list(lights), origin, device
+        a = _marshal_arrays(pos, uv, nrm, mat, materials, textures, root)
+        cl = (CLight * max(1, len(self.lights)))()
+        for i, l in enumerate(self.lights):
+            cl[i] = CLight(l.kind, 0, float(l.intensity), l.v._c())
+        flags = (FLAG_NO_CULL if no_cull else 0) | {None: 0, "lane": FLAG_LANE_FILTER, "bundle": FLAG_BUNDLE_FILTER, "ray": FLAG_RAY_WALK}[box_filter]
+        opt = COptions(0.0001, 5, flags, 1.0, 1.0, 1.0)
+        out = _P()
+        _check(lib().rrt_raytracer_create_from_arrays(a.n, _d(a.pos), _d(a.uv), _d(a.nrm), a.mat.ctypes.data_as(_u32p), len(materials), a.cm, len(a.keep), a.ct, a.r,
+                                                      cl, len(self.lights), origin._c(), C.byref(opt), device, C.byref(out)), "rrt_raytracer_create_from_arrays")
+        self._h = out
+        return self
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -434,7 +465,7 @@ class RayTracer:
     def setup_times(self) -> dict:
         """Wall ms of the once-per-scene stages: read, parse, texture decode, octree (model) + index, upload (this raytracer)."""
         t = CSetupTimes()
-        _check(lib().rrt_get_setup_times(self.scene_data._h, self._h, C.byref(t)), "rrt_get_setup_times")
+        _check(lib().rrt_get_setup_times(self.scene_data._h if self.scene_data is not None else None, self._h, C.byref(t)), "rrt_get_setup_times")
         return {n: getattr(t, n) for n, _ in CSetupTimes._fields_}
 
     def render_registered(self, width: int, height: int, fb: Optional[np.ndarray] = None) -> np.ndarray:

@@ -3,11 +3,13 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -431,21 +433,42 @@ namespace {
 // ids of rrt_raytracer_get_buffer (rrt.h: RRT_BUF_*)
 enum { kBufNodes = 0, kBufGeom, kBufAttr, kBufSupers, kBufCboxes, kBufChildBoxes, kBufTboxes, kBufSuspects, kBufOctBox, kBufOctFirstChild, kBufOctTriCount, kBufOctOwnOff, kBufOctOwnIdx, kBufSlotTri, kBufSlotPos, kBufCount };
 
-void upload_materials_and_textures(rrt_raytracer* rt, const Model& M, hipStream_t st, std::vector<DevTexture>& texs, std::vector<DevMaterial>& mats) {
-    texs.resize(M.textures.size());
+// what a set-up needs of a scene besides its triangles: materials and RGB8 textures (borrowed views)
+struct SceneTables { const rrt_material* mats; uint32_t n_mats; std::vector<rrt_texture> tex; };
+SceneTables tables_of(const Model& M) {
+    SceneTables T{M.materials.data(), (uint32_t)M.materials.size(), {}};
+    for (auto& t : M.textures) T.tex.push_back(rrt_texture{t.rgb.data(), t.width, t.height});
+    return T;
+}
+void validate_tables(const SceneTables& T) {
+    for (auto& t : T.tex) if (!t.rgb || t.width == 0 || t.height == 0) throw Error{RRT_ERR_INVALID_ARG, "texture with bad dimensions"};
+    for (uint32_t i = 0; i < T.n_mats; i++) {
+        const rrt_material& mat = T.mats[i];
+        if (mat.tex < 0 || (size_t)mat.tex >= T.tex.size()) throw Error{RRT_ERR_INVALID_ARG, "material texture index out of range"};
+        if (mat.bump >= (int32_t)T.tex.size()) throw Error{RRT_ERR_INVALID_ARG, "material bump index out of range"};
+        if (mat.bump >= 0) {   // see validate_model: the bump texel is addressed with the colour texture's (x, y) and the bump map's width (raytracer.rs:127-128)
+            const rrt_texture& t = T.tex[mat.tex]; const rrt_texture& b = T.tex[mat.bump];
+            if ((uint64_t)b.width * (t.height - 1) + (t.width - 1) >= (uint64_t)b.width * b.height)
+                throw Error{RRT_ERR_INVALID_ARG, "bump map too small for the texture whose texel indices address it (raytracer.rs:127-128 would index out of bounds)"};
+        }
+    }
+}
+
+void upload_materials_and_textures(rrt_raytracer* rt, const SceneTables& T, hipStream_t st, std::vector<DevTexture>& texs, std::vector<DevMaterial>& mats) {
+    texs.resize(T.tex.size());
     for (size_t i = 0; i < texs.size(); i++) {
         void* d = nullptr;
-        const size_t bytes = M.textures[i].rgb.size();
+        const size_t bytes = (size_t)3 * T.tex[i].width * T.tex[i].height;
         const size_t padded = (bytes + 255) & ~(size_t)255;
         if (rt->arena && rt->arena_used + padded <= rt->arena_bytes) { d = static_cast<char*>(rt->arena) + rt->arena_used; rt->arena_used += padded; }
         else { HIP_TRY(hipMalloc(&d, bytes ? bytes : 1)); rt->allocs.push_back(d); }
-        try { staged_upload(d, M.textures[i].rgb.data(), bytes, st); } catch (const HipBuildFail& f) { throw HipFail{(hipError_t)f.hip_error, f.what}; }
+        try { staged_upload(d, T.tex[i].rgb, bytes, st); } catch (const HipBuildFail& f) { throw HipFail{(hipError_t)f.hip_error, f.what}; }
         rt->scene_bytes += bytes;
-        texs[i].rgb = static_cast<const uint8_t*>(d); texs[i].width = M.textures[i].width; texs[i].height = M.textures[i].height;
+        texs[i].rgb = static_cast<const uint8_t*>(d); texs[i].width = T.tex[i].width; texs[i].height = T.tex[i].height;
     }
-    mats.resize(M.materials.size());
+    mats.resize(T.n_mats);
     for (size_t i = 0; i < mats.size(); i++) {
-        const rrt_material& s = M.materials[i]; DevMaterial& d = mats[i];
+        const rrt_material& s = T.mats[i]; DevMaterial& d = mats[i];
         d.ka[0] = s.ka.x; d.ka[1] = s.ka.y; d.ka[2] = s.ka.z; d.kd[0] = s.kd.x; d.kd[1] = s.kd.y; d.kd[2] = s.kd.z;
         d.ks[0] = s.ks.x; d.ks[1] = s.ks.y; d.ks[2] = s.ks.z; d.ns = s.ns; d.kr = s.kr; d.tex = s.tex; d.bump = s.bump;
         d.tex_desc = texs[s.tex]; d.bump_desc = s.bump >= 0 ? texs[s.bump] : DevTexture{nullptr, 0, 0};
@@ -513,7 +536,7 @@ void setup_on_host(rrt_raytracer* rt, const Model& M, rrt_vec3 origin, const rrt
         rt->arena_bytes = need;
     }
     std::vector<DevTexture> texs; std::vector<DevMaterial> mats;
-    upload_materials_and_textures(rt, M, nullptr, texs, mats);
+    upload_materials_and_textures(rt, tables_of(M), nullptr, texs, mats);
     DevScene& S = rt->scene;
     auto keep = [&](int id, const void* p, size_t bytes) { rt->bufs[id].p = p; rt->bufs[id].bytes = bytes; };
     S.nodes = upload(rt, nodes.get(), n_nodes);                              keep(kBufNodes, S.nodes, n_nodes * sizeof(DevNode));
@@ -550,7 +573,7 @@ void setup_on_host(rrt_raytracer* rt, const Model& M, rrt_vec3 origin, const rrt
 
 // ---- set-up on the GPU (default): the triangle array goes up through pinned staging, then octree, index and records are built there
 // (scene_build.hip).  Nothing of the tree ever exists on the host unless a getter asks for it.
-void setup_on_gpu(rrt_raytracer* rt, const Model& M, rrt_vec3 origin, const rrt_options& o, uint32_t& max_depth) {
+void setup_on_gpu(rrt_raytracer* rt, const TriSource& src, uint32_t n_tris, const Box& root, const SceneTables& T, rrt_vec3 origin, const rrt_options& o, uint32_t& max_depth) {
     using clk = std::chrono::steady_clock;
     const auto t0 = clk::now();
     const bool trace = std::getenv("RRT_SETUP_TRACE") != nullptr;
@@ -559,8 +582,8 @@ void setup_on_gpu(rrt_raytracer* rt, const Model& M, rrt_vec3 origin, const rrt_
     try { st = (hipStream_t)setup_stream(); } catch (const HipBuildFail& f) { throw HipFail{(hipError_t)f.hip_error, f.what}; }
     {   // textures + small tables: one allocation
         size_t need = (size_t)1 << 16;
-        for (auto& t : M.textures) need += t.rgb.size() + 256;
-        need += M.materials.size() * sizeof(DevMaterial) + M.textures.size() * sizeof(DevTexture) + 1024;
+        for (auto& t : T.tex) need += (size_t)3 * t.width * t.height + 256;
+        need += T.n_mats * sizeof(DevMaterial) + T.tex.size() * sizeof(DevTexture) + 1024;
         HIP_TRY(hipMalloc(&rt->arena, need));
         rt->allocs.push_back(rt->arena);
         rt->arena_bytes = need;
@@ -569,12 +592,12 @@ void setup_on_gpu(rrt_raytracer* rt, const Model& M, rrt_vec3 origin, const rrt_
     std::vector<DevTexture> texs; std::vector<DevMaterial> mats;
     GpuScene& G = rt->gs;
     const double org[3] = {origin.x, origin.y, origin.z};
-    try { gpu_build_scene(M.triangles.data(), (uint32_t)M.triangles.size(), M.root, !(o.flags & RRT_FLAG_NO_CULL), org, st, G); }
+    try { gpu_build_scene(src, n_tris, root, !(o.flags & RRT_FLAG_NO_CULL), org, st, G); }
     catch (const HipBuildFail& f) { if (G.scene_alloc) { (void)hipFree(G.scene_alloc); G.scene_alloc = nullptr; } throw HipFail{(hipError_t)f.hip_error, f.what}; }
     catch (...) { if (G.scene_alloc) { (void)hipFree(G.scene_alloc); G.scene_alloc = nullptr; } throw; }
     rt->allocs.push_back(G.scene_alloc);
     lap("gpu_build_scene");
-    upload_materials_and_textures(rt, M, st, texs, mats);
+    upload_materials_and_textures(rt, T, st, texs, mats);
     lap("texture upload enqueued");
     max_depth = G.max_depth;
     DevScene& S = rt->scene;
@@ -608,61 +631,97 @@ void setup_on_gpu(rrt_raytracer* rt, const Model& M, rrt_vec3 origin, const rrt_
     rt->octree_ms = G.ms_octree; rt->index_ms = G.ms_index;
     rt->upload_ms = std::chrono::duration<double, std::milli>(clk::now() - t0).count() - G.ms_octree - G.ms_index;   // uploads, allocations, synchronisation
     rrt_model_info& I = rt->tree_info;
-    I.n_tris = (uint32_t)M.triangles.size(); I.n_tris_in_tree = G.n_in_tree; I.n_nodes = G.n_nodes; I.max_depth = G.max_depth;
-    I.n_mats = (uint32_t)M.materials.size(); I.n_tex = (uint32_t)M.textures.size(); I.max_own_count = 0; I.root_own_count = 0;
+    I.n_tris = n_tris; I.n_tris_in_tree = G.n_in_tree; I.n_nodes = G.n_nodes; I.max_depth = G.max_depth;
+    I.n_mats = T.n_mats; I.n_tex = (uint32_t)T.tex.size(); I.max_own_count = 0; I.root_own_count = 0;
 }
 
+}  // namespace
+
+namespace {
+// rrt_raytracer_create and rrt_raytracer_create_from_arrays: everything but where the triangles come from
+int create_raytracer(const rrt_light* lights, uint32_t n_lights, rrt_vec3 origin, const rrt_options* opt, int device, rrt_raytracer** out,
+                     const std::function<void(rrt_raytracer*, const rrt_options&, uint32_t&)>& setup) {
+    if (!out || (n_lights && !lights)) throw Error{RRT_ERR_INVALID_ARG, "null argument"};
+    if (n_lights > RRT_MAX_LIGHTS) throw Error{RRT_ERR_INVALID_ARG, "too many lights (max 16)"};
+    for (uint32_t i = 0; i < n_lights; i++) if (lights[i].kind > 2) throw Error{RRT_ERR_INVALID_ARG, "bad light kind"};
+    rrt_options o;
+    if (opt) o = *opt; else { o.surface_offset = 0.0001; o.max_reflection_depth = 5; o.flags = 0; o.vp_w = o.vp_h = o.vp_d = 1.0; }
+    if (o.max_reflection_depth > RRT_MAX_REFLECT) throw Error{RRT_ERR_INVALID_ARG, "max_reflection_depth > 8"};
+    const auto t_create0 = std::chrono::steady_clock::now();
+    g_warmer.join();
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) { (void)hipGetLastError(); throw Error{RRT_ERR_NO_DEVICE, "no HIP device visible"}; }
+    if (device < 0 || device >= n_dev) throw Error{RRT_ERR_NO_DEVICE, "device index out of range"};
+    const auto t_init0 = std::chrono::steady_clock::now();
+    DeviceGuard guard(device);
+    HIP_TRY(hipFree(nullptr));                                          // brings the HIP context of this device up (a one-off of the process: ~90 ms on a fresh one)
+    const double hip_init_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_init0).count();
+
+    std::unique_ptr<rrt_raytracer, void (*)(rrt_raytracer*)> rt(new rrt_raytracer, rrt_raytracer_destroy);
+    rt->hip_init_ms = hip_init_ms;
+    rt->device = device; rt->opt = o;
+    uint32_t max_depth = 1;
+    setup(rt.get(), o, max_depth);
+
+    DevScene& S = rt->scene;
+    S.cull_enabled = (o.flags & RRT_FLAG_NO_CULL) ? 0u : 1u;
+    S.cull_half_over_limit = S.cull_limit > 0.0f ? 0.5f / S.cull_limit : 0.0f;
+    S.n_suspects = rt->n_suspects;
+    S.n_lights = n_lights; S.max_reflection_depth = o.max_reflection_depth; S.stack_levels = max_depth > 1 ? max_depth - 1 : 1;   // (stack_levels: only internal nodes push a frame; the deepest level holds leaves)
+    S.origin[0] = origin.x; S.origin[1] = origin.y; S.origin[2] = origin.z;
+    S.surface_offset = o.surface_offset;
+    for (uint32_t i = 0; i < n_lights; i++) {
+        S.lights[i].kind = lights[i].kind; S.lights[i]._pad = 0; S.lights[i].intensity = lights[i].intensity;
+        S.lights[i].v[0] = lights[i].v.x; S.lights[i].v[1] = lights[i].v.y; S.lights[i].v[2] = lights[i].v.z;
+    }
+#ifdef RRT_PROFILE
+    { void* pb = nullptr; HIP_TRY(hipMalloc(&pb, 32 * sizeof(unsigned long long))); HIP_TRY(hipMemset(pb, 0, 32 * sizeof(unsigned long long)));
+      rt->allocs.push_back(pb); S.prof = static_cast<unsigned long long*>(pb); }
+#endif
+    HIP_TRY(hipEventCreate(&rt->ev0)); HIP_TRY(hipEventCreate(&rt->ev1));
+    // Own-list filter variant: forced by a flag, else a measured rule on the first frame of each frame size and measured on the second (tune_variant)
+    rt->variant_forced = (o.flags & (RRT_FLAG_BUNDLE_FILTER | RRT_FLAG_LANE_FILTER | RRT_FLAG_RAY_WALK | RRT_FLAG_NO_CULL)) != 0;
+    rt->walk = (o.flags & RRT_FLAG_NO_CULL) ? 0 : (o.flags & RRT_FLAG_BUNDLE_FILTER) ? 1 : (o.flags & RRT_FLAG_RAY_WALK) ? 2 : 0;
+    rt->create_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create0).count();
+    *out = rt.release();
+    return RRT_OK;
+}
 }  // namespace
 
 int rrt_raytracer_create(const rrt_model* m, const rrt_light* lights, uint32_t n_lights, rrt_vec3 origin,
                          const rrt_options* opt, int device, rrt_raytracer** out) {
     return guarded([&]() -> int {
-        if (!m || !out || (n_lights && !lights)) throw Error{RRT_ERR_INVALID_ARG, "null argument"};
-        if (n_lights > RRT_MAX_LIGHTS) throw Error{RRT_ERR_INVALID_ARG, "too many lights (max 16)"};
-        for (uint32_t i = 0; i < n_lights; i++) if (lights[i].kind > 2) throw Error{RRT_ERR_INVALID_ARG, "bad light kind"};
-        rrt_options o;
-        if (opt) o = *opt; else { o.surface_offset = 0.0001; o.max_reflection_depth = 5; o.flags = 0; o.vp_w = o.vp_h = o.vp_d = 1.0; }
-        if (o.max_reflection_depth > RRT_MAX_REFLECT) throw Error{RRT_ERR_INVALID_ARG, "max_reflection_depth > 8"};
-        const auto t_create0 = std::chrono::steady_clock::now();
-        g_warmer.join();
-        int n_dev = 0;
-        if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) { (void)hipGetLastError(); throw Error{RRT_ERR_NO_DEVICE, "no HIP device visible"}; }
-        if (device < 0 || device >= n_dev) throw Error{RRT_ERR_NO_DEVICE, "device index out of range"};
-        const auto t_init0 = std::chrono::steady_clock::now();
-        DeviceGuard guard(device);
-        HIP_TRY(hipFree(nullptr));                                          // brings the HIP context of this device up (a one-off of the process: ~90 ms on a fresh one)
-        const double hip_init_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_init0).count();
-
-        std::unique_ptr<rrt_raytracer, void (*)(rrt_raytracer*)> rt(new rrt_raytracer, rrt_raytracer_destroy);
-        rt->hip_init_ms = hip_init_ms;
-        rt->device = device; rt->opt = o;
+        if (!m) throw Error{RRT_ERR_INVALID_ARG, "null argument"};
         const Model& M = m->m;
-        rt->gpu_setup = !(o.flags & RRT_FLAG_HOST_SETUP);
-        uint32_t max_depth = 1;
-        if (rt->gpu_setup) setup_on_gpu(rt.get(), M, origin, o, max_depth); else setup_on_host(rt.get(), M, origin, o, max_depth);
+        return create_raytracer(lights, n_lights, origin, opt, device, out, [&](rrt_raytracer* rt, const rrt_options& o, uint32_t& max_depth) {
+            rt->gpu_setup = !(o.flags & RRT_FLAG_HOST_SETUP);
+            if (rt->gpu_setup) { TriSource src; src.tris = M.triangles.data(); setup_on_gpu(rt, src, (uint32_t)M.triangles.size(), M.root, tables_of(M), origin, o, max_depth); }
+            else setup_on_host(rt, M, origin, o, max_depth);
+        });
+    });
+}
 
-        DevScene& S = rt->scene;
-        S.cull_enabled = (o.flags & RRT_FLAG_NO_CULL) ? 0u : 1u;
-        S.cull_half_over_limit = S.cull_limit > 0.0f ? 0.5f / S.cull_limit : 0.0f;
-        S.n_suspects = rt->n_suspects;
-        S.n_lights = n_lights; S.max_reflection_depth = o.max_reflection_depth; S.stack_levels = max_depth > 1 ? max_depth - 1 : 1;   // (stack_levels: only internal nodes push a frame; the deepest level holds leaves)
-        S.origin[0] = origin.x; S.origin[1] = origin.y; S.origin[2] = origin.z;
-        S.surface_offset = o.surface_offset;
-        for (uint32_t i = 0; i < n_lights; i++) {
-            S.lights[i].kind = lights[i].kind; S.lights[i]._pad = 0; S.lights[i].intensity = lights[i].intensity;
-            S.lights[i].v[0] = lights[i].v.x; S.lights[i].v[1] = lights[i].v.y; S.lights[i].v[2] = lights[i].v.z;
-        }
-#ifdef RRT_PROFILE
-        { void* pb = nullptr; HIP_TRY(hipMalloc(&pb, 32 * sizeof(unsigned long long))); HIP_TRY(hipMemset(pb, 0, 32 * sizeof(unsigned long long)));
-          rt->allocs.push_back(pb); S.prof = static_cast<unsigned long long*>(pb); }
-#endif
-        HIP_TRY(hipEventCreate(&rt->ev0)); HIP_TRY(hipEventCreate(&rt->ev1));
-        // Own-list filter variant: forced by a flag, else a rule of thumb on the first frame of each frame size and measured on the second (tune_variant)
-        rt->variant_forced = (o.flags & (RRT_FLAG_BUNDLE_FILTER | RRT_FLAG_LANE_FILTER | RRT_FLAG_RAY_WALK | RRT_FLAG_NO_CULL)) != 0;
-        rt->walk = (o.flags & RRT_FLAG_NO_CULL) ? 0 : (o.flags & RRT_FLAG_BUNDLE_FILTER) ? 1 : (o.flags & RRT_FLAG_RAY_WALK) ? 2 : 0;
-        rt->create_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create0).count();
-        *out = rt.release();
-        return RRT_OK;
+// RayTracer straight from the host's own arrays: rrt_model_from_arrays + rrt_raytracer_create without the model -- the arrays are uploaded from where
+// they lie (through the pinned staging ring) and packed into triangle records on the device, so the library keeps no host copy of the scene and the
+// loaders' copy (15 ms of the 1 M soup's 54 ms first frame) is not made.  Same scene in HBM, same frames.
+int rrt_raytracer_create_from_arrays(uint32_t n_tris, const double* pos, const double* uv, const double* nrm, const uint32_t* mat,
+                                     uint32_t n_mats, const rrt_material* mats, uint32_t n_tex, const rrt_texture* tex, const double* root,
+                                     const rrt_light* lights, uint32_t n_lights, rrt_vec3 origin, const rrt_options* opt, int device, rrt_raytracer** out) {
+    return guarded([&]() -> int {
+        if ((n_tris && (!pos || !uv || !nrm || !mat)) || (n_mats && !mats) || (n_tex && !tex)) throw Error{RRT_ERR_INVALID_ARG, "null argument"};
+        if (opt && (opt->flags & RRT_FLAG_HOST_SETUP)) throw Error{RRT_ERR_UNSUPPORTED, "RRT_FLAG_HOST_SETUP needs a model (rrt_model_from_arrays + rrt_raytracer_create)"};
+        SceneTables T{mats, n_mats, std::vector<rrt_texture>(tex, tex + n_tex)};
+        validate_tables(T);
+        std::atomic<bool> bad{false};
+        parallel_ranges(n_tris, 1 << 16, [&](size_t lo, size_t hi, size_t) { for (size_t i = lo; i < hi; i++) if (mat[i] >= n_mats) bad = true; });
+        if (bad) throw Error{RRT_ERR_INVALID_ARG, "triangle material index out of range"};
+        g_warmer.start();
+        const Box box = default_root(root);
+        return create_raytracer(lights, n_lights, origin, opt, device, out, [&](rrt_raytracer* rt, const rrt_options& o, uint32_t& max_depth) {
+            rt->gpu_setup = true;
+            TriSource src; src.pos = pos; src.uv = uv; src.nrm = nrm; src.mat = mat;
+            setup_on_gpu(rt, src, n_tris, box, T, origin, o, max_depth);
+        });
     });
 }
 

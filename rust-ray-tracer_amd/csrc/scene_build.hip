@@ -556,6 +556,18 @@ __global__ void __launch_bounds__(kBlock) k_suspects(const Triangle* tris, const
     out[k] = q;
 }
 
+// the caller's arrays -> Triangle records (rrt_raytracer_create_from_arrays): the layout rrt_model_from_arrays produces on the host
+__global__ void __launch_bounds__(kBlock) k_pack_triangles(const double* __restrict__ pos, const double* __restrict__ uv, const double* __restrict__ nrm, const uint32_t* __restrict__ mat, uint32_t n, Triangle* __restrict__ out) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    auto rd = [](const double* p) { Vec3 v; v.x = p[0]; v.y = p[1]; v.z = p[2]; return v; };
+    Triangle t;
+    t.v1 = rd(pos + 9 * (size_t)i); t.v2 = rd(pos + 9 * (size_t)i + 3); t.v3 = rd(pos + 9 * (size_t)i + 6);
+    t.t1 = rd(uv + 9 * (size_t)i);  t.t2 = rd(uv + 9 * (size_t)i + 3);  t.t3 = rd(uv + 9 * (size_t)i + 6);
+    t.n1 = rd(nrm + 9 * (size_t)i); t.n2 = rd(nrm + 9 * (size_t)i + 3); t.n3 = rd(nrm + 9 * (size_t)i + 6);
+    t.mat = mat[i]; t._pad = 0;
+    out[i] = t;
+}
 __global__ void k_set_root(Oct S) {
     for (int a = 0; a < 3; a++) { S.nbox[a] = S.rlo[a]; S.nbox[3 + a] = S.rhi[a]; }
     S.first[0] = kNone; S.second[0] = kNone; S.cnt[0] = 0u; S.child_base[0] = 0u; S.ctr[0] = 0u; S.ctr[1] = 0u;
@@ -687,7 +699,7 @@ void staged_download(void* dst, const void* src_dev, size_t bytes, void* stream_
     }
 }
 
-void gpu_build_scene(const Triangle* tris, uint32_t n, const Box& root, bool enable_cull, const double origin[3], void* stream_, GpuScene& out) {
+void gpu_build_scene(const TriSource& src, uint32_t n, const Box& root, bool enable_cull, const double origin[3], void* stream_, GpuScene& out) {
     hipStream_t st = (hipStream_t)stream_;
     const bool trace = std::getenv("RRT_SETUP_TRACE") != nullptr;          // developer: host wall time of every stage (synchronising: not the production timing)
     auto lap = [&, last = std::chrono::steady_clock::now()](const char* what) mutable {
@@ -712,14 +724,19 @@ void gpu_build_scene(const Triangle* tris, uint32_t n, const Box& root, bool ena
     const size_t prim_bytes = std::max(scan_bytes, sort_bytes) + 256;
     DevFree t1;
     DevArena A1;
-    A1.cap = (size_t)n * (sizeof(Triangle) + 48 + 3 * 4 + 4 /*rank*/ + 4 * 4 /*key,val in/out*/) + cap * (48 + 4 * 4) + (cap / 8 + 1) * 8 + prim_bytes + (64 << 10);
+    A1.cap = (size_t)n * (sizeof(Triangle) + (src.tris ? 0 : 27 * 8 + 4) + 48 + 3 * 4 + 4 /*rank*/ + 4 * 4 /*key,val in/out*/) + cap * (48 + 4 * 4) + (cap / 8 + 1) * 8 + prim_bytes + (64 << 10);
     lap("events, rocPRIM size queries");
     HB_TRY(hipMalloc(&t1.p, A1.cap)); A1.base = static_cast<char*>(t1.p);
     lap("hipMalloc temporaries 1");
 
     HB_TRY(hipEventRecord(evs[0], st));
     Triangle* d_tris = A1.take<Triangle>(n);
-    staged_upload(d_tris, tris, sizeof(Triangle) * (size_t)n, st);
+    if (src.tris) staged_upload(d_tris, src.tris, sizeof(Triangle) * (size_t)n, st);
+    else if (n) {
+        double* d_pos = A1.take<double>(9 * (size_t)n), *d_uv = A1.take<double>(9 * (size_t)n), *d_nrm = A1.take<double>(9 * (size_t)n); uint32_t* d_mat = A1.take<uint32_t>(n);
+        staged_upload(d_pos, src.pos, 72 * (size_t)n, st); staged_upload(d_uv, src.uv, 72 * (size_t)n, st); staged_upload(d_nrm, src.nrm, 72 * (size_t)n, st); staged_upload(d_mat, src.mat, 4 * (size_t)n, st);
+        hipLaunchKernelGGL(k_pack_triangles, dim3(grid_for(n)), dim3(kBlock), 0, st, d_pos, d_uv, d_nrm, d_mat, n, d_tris);
+    }
     HB_TRY(hipEventRecord(evs[1], st));
     lap("triangle upload (pinned staging)");
 

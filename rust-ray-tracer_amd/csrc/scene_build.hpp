@@ -31,7 +31,10 @@ struct GpuScene {
 // Builds the scene on the current HIP device from `tris` (HOST array, uploaded here through pinned staging).  enable_cull = !RRT_FLAG_NO_CULL.
 // Throws rrt::Error (RRT_ERR_DEPTH when the octree is deeper than RRT_MAX_OCTREE_DEPTH) or HipBuildFail.  The caller owns out.scene_alloc (hipFree).
 struct HipBuildFail { int hip_error; const char* what; };
-void gpu_build_scene(const Triangle* tris, uint32_t n_tris, const Box& root, bool enable_cull, const double origin[3], void* stream, GpuScene& out);
+// The triangles either as the model's array (Triangle records, SceneData.triangles) or as the caller's own arrays (rrt_raytracer_create_from_arrays:
+// pos / uv / nrm [n][3][3] doubles, mat [n]) -- those are uploaded as they are and packed into Triangle records on the device.
+struct TriSource { const Triangle* tris = nullptr; const double* pos = nullptr; const double* uv = nullptr; const double* nrm = nullptr; const uint32_t* mat = nullptr; };
+void gpu_build_scene(const TriSource& src, uint32_t n_tris, const Box& root, bool enable_cull, const double origin[3], void* stream, GpuScene& out);
 
 // Pinned-staging upload of a host buffer (pageable or not) to device memory on `stream`: worker threads fill a ring of page-locked chunks while
 // the DMA engine drains it.  Returns after the last chunk has been ENQUEUED and copied out of `src` (src may be freed; dst is ready after a stream sync).

@@ -87,6 +87,7 @@ def test_round2_entry_points_validate_their_arguments_without_a_gpu(rrt, teapot)
     assert t.parse_ms > 0 and t.texture_ms > 0 and t.octree_ms > 0 and t.index_ms == 0 and t.upload_ms == 0 and t.create_ms == 0
     assert L.rrt_raytracer_get_octree(None, None, None, None, None, None, None) == rrt.ERR_INVALID_ARG
     assert L.rrt_raytracer_get_buffer(None, 0, None, 0, None) == rrt.ERR_INVALID_ARG
+    assert L.rrt_raytracer_create_from_arrays(3, None, None, None, None, 0, None, 0, None, None, None, 0, rrt.Vec3(0, 0, 0), None, 0, C.byref(out)) == rrt.ERR_INVALID_ARG
     assert L.rrt_get_setup_times(None, None, None) == rrt.ERR_INVALID_ARG
 
 

@@ -156,3 +156,24 @@ def test_too_deep_octree_is_rejected_by_the_gpu_build(rrt):
     assert e.value.status == rrt.ERR_DEPTH
     sd40 = scene_from(rrt, [[p, p, p]] * 40)                                # exactly RRT_MAX_OCTREE_DEPTH levels: accepted by both
     assert rrt.RayTracer(sd40, rrt.default_lights()).octree()["max_depth"] == 40 == sd40.info["max_depth"]
+
+
+def test_raytracer_straight_from_arrays_builds_the_same_scene(rrt):
+    """rrt_raytracer_create_from_arrays (no rrt_model: the caller's arrays are uploaded from where they lie and packed into triangle records on the device)
+    puts the same bytes into HBM as rrt_model_from_arrays + rrt_raytracer_create, renders the same frame, and validates its inputs the same way."""
+    sd = rrt.parse_obj_file(os.path.join(ASSETS, "model2.obj"))
+    pos, uv, nrm, mat = sd.triangles(); mats, texs = sd.materials(), sd.textures()
+    lights = rrt.default_lights()
+    via_model = rrt.RayTracer(rrt.SceneData.from_arrays(pos, uv, nrm, mat, mats, texs), lights)
+    direct = rrt.RayTracer.from_arrays(pos, uv, nrm, mat, mats, texs, lights)
+    assert_same_buffers(direct, via_model, "from arrays")
+    assert_same_octree(direct.octree(), via_model.octree(), "from arrays")
+    assert np.array_equal(direct.render(320, 200), via_model.render(320, 200))
+    t = direct.setup_times()
+    assert t["gpu_setup"] == 1.0 and t["octree_ms"] > 0 and t["parse_ms"] == 0
+    with pytest.raises(rrt.RrtError) as e:
+        rrt.RayTracer.from_arrays(pos, uv, nrm, np.full(len(mat), 99, np.uint32), mats, texs, lights)
+    assert e.value.status == rrt.ERR_INVALID_ARG
+    empty = rrt.RayTracer.from_arrays(np.zeros((0, 3, 3)), np.zeros((0, 3, 3)), np.zeros((0, 3, 3)), np.zeros(0, np.uint32), mats, texs, lights)
+    f = empty.render(64, 48)
+    assert (f[1:, :64] == 0xFFFFFF).all() and (f[0] == 0).all()
