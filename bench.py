@@ -117,6 +117,7 @@ def supervise(args, argv) -> int:
         child = [os.path.abspath(__file__)] + base + ["--gather", path, "--child"]
         if under_launcher:
             env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 11 + k)
+            env.pop("TORCHELASTIC_USE_AGENT_STORE", None)      # the children rendezvous among themselves: rank 0's child hosts the store on the new port
             cmd = [sys.executable] + child
         elif force_one:
             env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29533")) + k)

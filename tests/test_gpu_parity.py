@@ -520,3 +520,28 @@ def test_direction_magnitude_does_not_matter_to_the_index(rrt, teapot, scale):
     for mode in ("lane", "bundle", "ray"):
         got = rrt.RayTracer(teapot, rrt.default_lights(), box_filter=mode).intersect_rays(o, d * scale)
         for x, y in zip(got, ref): assert np.array_equal(x, y), (mode, scale)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_in_both_launch_modes_rehearsal():
+    """bench.py --gpus 2 end to end with TWO rank processes (RRT_BENCH_REHEARSAL=1: both ranks on this box's one GPU, the collective over gloo -- RCCL refuses
+    two ranks on one device; numbers from it are not results): (a) started plainly -- the GPU-free supervisor starts one torch.distributed.run per gather
+    path; (b) started the way the driver does, as ranks under torch.distributed.run -- every rank supervises its own children, which rendezvous on a port of
+    their own.  Either way: rc 0, exactly one JSON line, n_gpus 2, and the gathered, de-tiled frame is the single-GPU frame."""
+    import json, subprocess, sys
+    root = os.path.dirname(ASSETS)
+    common = ["--no-cpu-baseline", "--steps", "4", "--warmup", "1", "--width", "320", "--height", "240", "--torch-timeout", "240", "--lib-timeout", "240"]
+    def one_line(r):
+        assert r.returncode == 0, (r.stdout[-800:], r.stderr[-2500:])
+        lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+        assert len(lines) == 1, r.stdout
+        return json.loads(lines[0])
+    port = 29700 + os.getpid() % 200
+    env = dict(os.environ, RRT_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    single = one_line(subprocess.run([sys.executable, os.path.join(root, "bench.py"), *common, "--no-first-frame", "--no-host-fb"], capture_output=True, text=True, env=dict(os.environ), timeout=600))
+    plain = one_line(subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", *common], capture_output=True, text=True, env=env, timeout=900))
+    launched = one_line(subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port + 40),
+                                        os.path.join(root, "bench.py"), "--gpus", "2", *common], capture_output=True, text=True, env=dict(os.environ, RRT_BENCH_REHEARSAL="1"), timeout=900))
+    for out in (plain, launched):
+        assert out["n_gpus"] == 2 and out["frame_checksum"] == single["frame_checksum"] and "rehearsal" in out and set(out["gather_paths"]) == {"torch", "lib"}
+        assert all("error" not in v for v in out["gather_paths"].values()), out["gather_paths"]
