@@ -14,6 +14,7 @@
 #include <cstring>
 
 #include "model.hpp"
+#include "parallel.hpp"
 
 namespace rrt {
 namespace {
@@ -36,11 +37,20 @@ struct Huff {
     bool present = false;
     uint8_t vals[256];
     int32_t mincode[17], maxcode[18], valptr[17];
+    static constexpr int kLook = 9;
+    uint16_t look[1 << kLook];       // the next 9 bits -> (code length << 8 | symbol) for codes of <= 9 bits, 0 = longer code (bit-by-bit path)
     void build(const uint8_t counts[16], const uint8_t* symbols, int nsym) {
         std::memcpy(vals, symbols, nsym);
+        std::memset(look, 0, sizeof look);
         int code = 0, k = 0;
         for (int len = 1; len <= 16; len++) {
             valptr[len] = k; mincode[len] = code;
+            if (len <= kLook)
+                for (int j = 0; j < counts[len - 1] && k + j < nsym; j++) {
+                    const int c = (code + j) << (kLook - len);
+                    if (c + (1 << (kLook - len)) > (1 << kLook)) break;   // (an over-subscribed table of a hostile file: leave it to the slow path, which rejects it)
+                    for (int f = 0; f < (1 << (kLook - len)); f++) look[c + f] = (uint16_t)((len << 8) | symbols[k + j]);
+                }
             code += counts[len - 1]; k += counts[len - 1];
             maxcode[len] = counts[len - 1] ? code - 1 : -1;
             code <<= 1;
@@ -50,31 +60,36 @@ struct Huff {
     }
 };
 
+// Bits of the entropy-coded segment, most significant first.  A 0xFF00 pair is the byte 0xFF; any other 0xFF xx is a marker: it is left for the
+// caller and zeros are fed from there on (as libjpeg does for a truncated scan).
 struct BitReader {
     const uint8_t* p; const uint8_t* end;
-    uint32_t acc = 0; int nbits = 0;
+    uint64_t acc = 0; int nbits = 0;      // the low `nbits` bits of acc are the unread bits
     bool hit_marker = false;
-    int bit() {
-        if (nbits == 0) {
+    void fill() {
+        while (nbits <= 56) {
             uint8_t b = 0;
             if (!hit_marker && p < end) {
                 b = *p++;
                 if (b == 0xFF) {
-                    uint8_t b2 = p < end ? *p : 0;
-                    if (b2 == 0) p++;                 // stuffed zero
-                    else { hit_marker = true; p--; b = 0; }   // a marker: feed zeros, leave it for the caller
+                    const uint8_t b2 = p < end ? *p : 0;
+                    if (b2 == 0) p++;                              // stuffed zero
+                    else { hit_marker = true; p--; b = 0; }        // a marker: feed zeros, leave it for the caller
                 }
             }
-            acc = b; nbits = 8;
+            acc = (acc << 8) | b; nbits += 8;
         }
-        nbits--;
-        return (acc >> nbits) & 1;
     }
-    int bits(int n) { int v = 0; while (n--) v = (v << 1) | bit(); return v; }
-    void reset() { acc = 0; nbits = 0; hit_marker = false; }
+    int peek(int n) { if (nbits < n) fill(); return (int)((acc >> (nbits - n)) & ((1u << n) - 1u)); }
+    void skip(int n) { nbits -= n; }
+    int bit() { const int v = peek(1); skip(1); return v; }
+    int bits(int n) { if (n == 0) return 0; const int v = peek(n); skip(n); return v; }
+    void reset_at(const uint8_t* q) { p = q; acc = 0; nbits = 0; hit_marker = false; }
 };
 
 inline int decode_symbol(BitReader& br, const Huff& h) {
+    const uint16_t e = h.look[br.peek(Huff::kLook)];
+    if (e) { br.skip(e >> 8); return e & 0xFF; }
     int code = 0;
     for (int len = 1; len <= 16; len++) {
         code = (code << 1) | br.bit();
@@ -123,7 +138,7 @@ void idct_islow(const int32_t in[64], uint8_t* out, size_t stride) {
     }
 }
 
-struct Component { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0; int pred = 0; std::vector<uint8_t> plane; };
+struct Component { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0; int pred = 0; };
 
 void decode_jpeg(const std::vector<uint8_t>& buf, std::vector<uint8_t>& out, uint32_t& W, uint32_t& H, uint32_t& channels) {
     const uint8_t* p = buf.data(); const uint8_t* end = p + buf.size();
@@ -196,68 +211,82 @@ void decode_jpeg(const std::vector<uint8_t>& buf, std::vector<uint8_t>& out, uin
 
     const uint32_t bw = (W + 7) / 8, bh = (H + 7) / 8;
     const size_t stride = (size_t)bw * 8;
-    for (auto& c : comps) c.plane.assign(stride * bh * 8, 0);
+    // ---- phase 1, sequential by nature: the entropy-coded segment -> quantised coefficients (natural order) of every block of every component
+    const size_t n_blocks = (size_t)bw * bh, nc = comps.size();
+    std::vector<int16_t> coef(n_blocks * nc * 64, 0);
     BitReader br{p, end};
-    int to_restart = restart_interval; int next_rst = 0;
+    int to_restart = restart_interval;
     for (uint32_t by = 0; by < bh; by++) {
         for (uint32_t bx = 0; bx < bw; bx++) {
             if (restart_interval && to_restart == 0) {
-                // byte-align, expect RSTn
+                // byte-align, expect RSTn (the reader never passes a marker: it is at or ahead of br.p)
                 const uint8_t* q = br.p;
                 while (q + 1 < end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) q++;
                 if (q + 1 >= end) fail(RRT_ERR_PARSE, "Cannot decode texture file: missing RST");
-                (void)next_rst; next_rst = (next_rst + 1) & 7;
-                br.p = q + 2; br.reset();
+                br.reset_at(q + 2);
                 for (auto& c : comps) c.pred = 0;
                 to_restart = restart_interval;
             }
-            for (auto& c : comps) {
-                int32_t blk[64] = {};
+            for (size_t ci = 0; ci < nc; ci++) {
+                Component& c = comps[ci];
+                int16_t* blk = &coef[(((size_t)by * bw + bx) * nc + ci) * 64];
                 int t = decode_symbol(br, dc[c.td]);
                 if (t > 11) fail(RRT_ERR_PARSE, "Cannot decode texture file: bad DC category");          // 8-bit JPEG: DC differences have at most 11 bits
                 int diff = t ? extend(br.bits(t), t) : 0;
                 c.pred += diff;
                 if (c.pred < -32768 || c.pred > 32767) fail(RRT_ERR_PARSE, "Cannot decode texture file: DC predictor out of range");
-                blk[0] = c.pred * qt[c.tq][0];
+                blk[0] = (int16_t)c.pred;
                 for (int k = 1; k < 64;) {
                     int rs = decode_symbol(br, ac[c.ta]);
                     int r = rs >> 4, sz = rs & 15;
                     if (sz == 0) { if (r == 15) { k += 16; continue; } break; }
                     k += r;
                     if (k > 63) fail(RRT_ERR_PARSE, "Cannot decode texture file: bad AC run");
-                    int z = kZigzag[k];
                     if (sz > 10) fail(RRT_ERR_PARSE, "Cannot decode texture file: bad AC size");                // 8-bit JPEG: AC coefficients have at most 10 bits
-                    blk[z] = extend(br.bits(sz), sz) * qt[c.tq][z];
+                    blk[kZigzag[k]] = (int16_t)extend(br.bits(sz), sz);
                     k++;
                 }
-                for (int k = 0; k < 64; k++) blk[k] = blk[k] < -(1 << 15) ? -(1 << 15) : blk[k] > (1 << 15) ? (1 << 15) : blk[k];   // hostile tables: keep the IDCT inside int32 (a valid file never gets near)
-                idct_islow(blk, c.plane.data() + (size_t)by * 8 * stride + (size_t)bx * 8, stride);
             }
             if (restart_interval) to_restart--;
         }
     }
 
-    if (comps.size() == 1) {
-        channels = 1; out.resize((size_t)W * H);
-        for (uint32_t y = 0; y < H; y++) std::memcpy(out.data() + (size_t)y * W, comps[0].plane.data() + y * stride, W);
-        return;
-    }
-    channels = 3; out.resize((size_t)W * H * 3);
-    const bool ycc = adobe_transform < 0 ? !(comps[0].id == 'R' && comps[1].id == 'G' && comps[2].id == 'B') : adobe_transform != 0;
+    // ---- phase 2, every row of blocks on its own: dequantise, inverse DCT, colour conversion (a 1024 x 1024 texture: 3 x 16 384 blocks -- the larger
+    // part of the decode, and the part the host's cores can share)
+    const bool grey = nc == 1;
+    channels = grey ? 1 : 3; out.resize((size_t)W * H * channels);
+    const bool ycc = adobe_transform < 0 ? !(!grey && comps[0].id == 'R' && comps[1].id == 'G' && comps[2].id == 'B') : adobe_transform != 0;
     // IJG jdcolor.c: 16.16 fixed point, FIX(x) = (int)(x*65536 + 0.5)
     constexpr int32_t ONE_HALF = 1 << 15, F1_402 = 91881, F1_772 = 116130, F0_714 = 46802, F0_344 = 22554;
-    for (uint32_t y = 0; y < H; y++) {
-        const uint8_t* Y = comps[0].plane.data() + y * stride; const uint8_t* Cb = comps[1].plane.data() + y * stride; const uint8_t* Cr = comps[2].plane.data() + y * stride;
-        uint8_t* o = out.data() + (size_t)y * W * 3;
-        for (uint32_t x = 0; x < W; x++) {
-            if (!ycc) { o[3 * x] = Y[x]; o[3 * x + 1] = Cb[x]; o[3 * x + 2] = Cr[x]; continue; }
-            int32_t yy = Y[x], cb = Cb[x] - 128, cr = Cr[x] - 128;
-            int32_t r = yy + ((F1_402 * cr + ONE_HALF) >> 16);
-            int32_t g = yy + ((-F0_344 * cb + ONE_HALF - F0_714 * cr) >> 16);
-            int32_t b = yy + ((F1_772 * cb + ONE_HALF) >> 16);
-            o[3 * x] = clamp255(r); o[3 * x + 1] = clamp255(g); o[3 * x + 2] = clamp255(b);
+    parallel_ranges(bh, 4, [&](size_t rb, size_t re, size_t) {
+        std::vector<uint8_t> rows(nc * 8 * stride);                      // the 8 pixel rows of one row of blocks, per component
+        for (size_t by = rb; by < re; by++) {
+            for (uint32_t bx = 0; bx < bw; bx++)
+                for (size_t ci = 0; ci < nc; ci++) {
+                    const int16_t* q = &coef[((by * bw + bx) * nc + ci) * 64];
+                    const uint16_t* t = qt[comps[ci].tq];
+                    int32_t blk[64];
+                    for (int k = 0; k < 64; k++) { const int32_t v = (int32_t)q[k] * t[k]; blk[k] = v < -(1 << 15) ? -(1 << 15) : v > (1 << 15) ? (1 << 15) : v; }   // hostile tables: keep the IDCT inside int32 (a valid file never gets near)
+                    idct_islow(blk, rows.data() + ci * 8 * stride + (size_t)bx * 8, stride);
+                }
+            for (uint32_t r = 0; r < 8; r++) {
+                const size_t y = by * 8 + r;
+                if (y >= H) break;
+                const uint8_t* Y = rows.data() + r * stride;
+                if (grey) { std::memcpy(out.data() + y * W, Y, W); continue; }
+                const uint8_t* Cb = rows.data() + (8 + r) * stride; const uint8_t* Cr = rows.data() + (16 + r) * stride;
+                uint8_t* o = out.data() + y * W * 3;
+                for (uint32_t x = 0; x < W; x++) {
+                    if (!ycc) { o[3 * x] = Y[x]; o[3 * x + 1] = Cb[x]; o[3 * x + 2] = Cr[x]; continue; }
+                    int32_t yy = Y[x], cb = Cb[x] - 128, cr = Cr[x] - 128;
+                    int32_t rr = yy + ((F1_402 * cr + ONE_HALF) >> 16);
+                    int32_t g = yy + ((-F0_344 * cb + ONE_HALF - F0_714 * cr) >> 16);
+                    int32_t b = yy + ((F1_772 * cb + ONE_HALF) >> 16);
+                    o[3 * x] = clamp255(rr); o[3 * x + 1] = clamp255(g); o[3 * x + 2] = clamp255(b);
+                }
+            }
         }
-    }
+    });
 }
 
 // ===================================================================== PNG
