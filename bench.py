@@ -468,13 +468,26 @@ def main() -> None:
                 t2 = time.perf_counter()
                 return {"first_frame_ms": round((t2 - t0) * 1e3, 2), "raytracer_create_from_arrays_ms": round((t1 - t0) * 1e3, 2), "first_render_ms": round((t2 - t1) * 1e3, 2),
                         "identical_to_steady_frame": bool(np.array_equal(f, frame))}
+            def cold_from_file():
+                t0 = time.perf_counter()
+                sd2 = rrt.parse_obj_file(args.scene)
+                t1 = time.perf_counter()
+                rt2 = rrt.RayTracer(sd2, lights, rrt.DEFAULT_ORIGIN, device=local_rank)
+                t2 = time.perf_counter()
+                f = rt2.render(W, H)
+                t3 = time.perf_counter()
+                st = rt2.setup_times()
+                return {"first_frame_ms": round((t3 - t0) * 1e3, 2), "parse_obj_file_ms": round((t1 - t0) * 1e3, 2), "of_it_texture_decode_ms": round(st["texture_ms"], 2),
+                        "raytracer_create_ms": round((t2 - t1) * 1e3, 2), "first_render_ms": round((t3 - t2) * 1e3, 2), "identical_to_steady_frame": bool(np.array_equal(f, frame))}
             runs = [cold(False) for _ in range(3)]
             first = dict(sorted(runs, key=lambda r: r["first_frame_ms"])[1], runs_ms=[r["first_frame_ms"] for r in runs])
             first["host_setup"] = cold(True)
             first["without_model"] = sorted([cold_direct() for _ in range(3)], key=lambda r: r["first_frame_ms"])[1]
+            first["from_file"] = sorted([cold_from_file() for _ in range(3)], key=lambda r: r["first_frame_ms"])[1]
             first["note"] = ("median of 3 cold runs: rrt_model_from_arrays -> rrt_raytracer_create (GPU set-up: pinned-staging upload, octree.rs:41-241 level-parallel on the device, index, "
                              "records) -> first rrt_render into a pageable host framebuffer; `host_setup` = the same with RRT_FLAG_HOST_SETUP (round-2 path), once; "
-                             "`without_model` = rrt_raytracer_create_from_arrays -> first rrt_render (the host's arrays uploaded from where they lie, no rrt_model copy), median of 3")
+                             "`without_model` = rrt_raytracer_create_from_arrays -> first rrt_render (the host's arrays uploaded from where they lie, no rrt_model copy), median of 3; "
+                             "`from_file` = rrt_model_load_obj (.obj/.mtl parse + JPEG decode on the host) -> rrt_raytracer_create -> first rrt_render: the reference's whole run, median of 3")
 
         # --- work counters for the reference algorithm's flop count (oracle counters; committed for the headline config, else scaled from the CPU sample)
         counters, counters_src = None, None
