@@ -715,6 +715,7 @@ void gpu_build_scene(const TriSource& src, uint32_t n, const Box& root, bool ena
     // ---- temporaries, first part: everything whose size follows from the triangle count.  A subdivision has a distinct trigger triangle and
     // triangle 0 triggers none, so there are at most n - 1 of them: 1 + 8 (n - 1) nodes bound every scene.
     const size_t cap = 1 + 8 * (size_t)(n > 1 ? n - 1 : 0) + 8;
+    if (cap > 0xFFFFFF00ull) throw Error{RRT_ERR_UNSUPPORTED, "more than 2^29 triangles: node ids are 32 bits wide"};
     size_t scan_bytes = 0, sort_bytes = 0;
     {
         size_t b = 0;
