@@ -145,6 +145,41 @@ def test_jpeg_decoder_matches_libjpeg(rrt):
         assert np.array_equal(ours, ref), name
 
 
+def test_jpeg_decoder_on_synthetic_files(rrt, tmp_path):
+    """The table-driven entropy decoder and the two-phase (sequential Huffman, parallel inverse DCT) structure against libjpeg on files the scene does not
+    hold: odd sizes (partial edge blocks), low and high quality (long and short Huffman codes: the 9-bit lookup and the bit-by-bit path), restart
+    intervals (the marker search of a reader that buffers ahead), greyscale (decoded, then refused by the RGB8 entry point), and truncated files
+    (libjpeg pads a truncated scan with zeros; the decoder must not read out of bounds or fail differently for any cut)."""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(9)
+    smooth = np.clip(np.cumsum(rng.normal(size=(67, 131, 3)), axis=1) * 6 + 128, 0, 255).astype(np.uint8)
+    noise = rng.integers(0, 256, (40, 24, 3), dtype=np.uint8)
+    n = 0
+    for img in (smooth, noise, smooth[:8, :8], smooth[:1, :1], noise[:9, :17]):
+        for q in (5, 50, 93, 100):
+            for extra in ({}, {"restart_marker_blocks": 3}, {"restart_marker_rows": 1}):
+                p = tmp_path / f"s{n}.jpg"; n += 1
+                try:
+                    Image.fromarray(img).save(p, quality=q, subsampling=0, **extra)
+                except TypeError:
+                    continue                                               # an older Pillow without restart-marker options
+                ref = np.asarray(Image.open(p).convert("RGB"))
+                assert np.array_equal(rrt.decode_image_file(str(p)), ref), (img.shape, q, extra)
+    g = tmp_path / "grey.jpg"
+    Image.fromarray(smooth[..., 0]).save(g, quality=80)
+    with pytest.raises(rrt.RrtError) as e:
+        rrt.decode_image_file(str(g))
+    assert e.value.status == rrt.ERR_UNSUPPORTED
+    data = open(tmp_path / "s1.jpg", "rb").read()
+    for cut in (len(data) // 3, len(data) // 2, len(data) - 3, 200, 30):
+        t = tmp_path / "cut.jpg"; t.write_bytes(data[:cut])
+        try:
+            out = rrt.decode_image_file(str(t))
+            assert out.shape == smooth.shape
+        except rrt.RrtError as e2:
+            assert e2.status in (rrt.ERR_PARSE, rrt.ERR_UNSUPPORTED)
+
+
 def test_png_decoder(rrt, tmp_path):
     Image = pytest.importorskip("PIL.Image")
     rng = np.random.default_rng(1)
