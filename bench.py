@@ -528,6 +528,7 @@ def main() -> None:
             if div == 1:
                 d = np.abs(np.stack([(frame >> s) & 255 for s in (16, 8, 0)], -1).astype(np.int64) - np.stack([(ref >> s) & 255 for s in (16, 8, 0)], -1).astype(np.int64))
                 cpu["gpu_vs_cpu_max_channel_diff"] = int(d.max())
+                cpu["gpu_vs_cpu_pixels_with_nonzero_diff"] = int((d.max(-1) > 0).sum())      # of the whole frame (stated tolerance: 1 per channel, for pow)
             if counters is None:
                 scale = (rays_primary + 4 * 2 * (W // 2)) / cpu_rays
                 counters = {k: v * scale for k, v in cnt.items()}
