@@ -725,8 +725,31 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
     for (;;) {
         const unsigned long long pending = __builtin_amdgcn_ballot_w64(!done);
         if (pending == 0) break;
-#ifndef RRT_LEADER_FIRST   // default: min-id leader (6 % faster on the 100k soup, neutral on the teapot); -DRRT_LEADER_FIRST = first pending lane
-        const uint32_t unode = wave_min_u32(done ? 0xFFFFFFFFu : cur);   // the pending node with the smallest id: keeps lanes that share nodes in step
+#ifndef RRT_LEADER_FIRST   // default: a wave-wide reduction picks the node (below); -DRRT_LEADER_FIRST = the first pending lane's node (round 1: 6 % slower than smallest-id on the 100k soup)
+        // WHICH pending node the wave visits next decides how many lanes share a visit, and a visit costs the same ~800 instructions whoever takes part.
+        // Round 3: the DEEPEST pending lane's node (ties: smallest id) -- depth-first for the wave as a whole.  Lanes deep in the tree finish their
+        // subtrees and come back up to where the others are parked before those nodes are processed, so a node is visited once with everybody who will
+        // ever need it, instead of early with few lanes and again for the late-comers (rounds 1-2 took the smallest id, a breadth-first-like order:
+        // 17.8 of 64 lanes per visit on the 100 k soup).  Any order gives the same per-lane results.  100 k soup 11.8 -> 8.9 ms, 1 M soup 26.0 -> 22.9 ms,
+        // teapot 0.894 -> 0.882 ms (profiles/r03_ab_pick_policy.txt; largest id first: 8.95 / 23.5; shallowest first: 11.87 / 26.06).
+#ifndef RRT_PICK_POLICY
+#define RRT_PICK_POLICY 3
+#endif
+#ifndef RRT_PICK_POLICY_BUNDLE
+#define RRT_PICK_POLICY_BUNDLE 0   /* the bundle-filter kernel (coherent frames) is insensitive to the order: 0.868 ms either way; it keeps the rounds-1-2 pick */
+#endif
+        constexpr int kPick = kBundle ? RRT_PICK_POLICY_BUNDLE : RRT_PICK_POLICY;
+        uint32_t unode;
+        if constexpr (kPick == 3) {
+            // deepest pending lane first, ties to the smaller id.  The key keeps 26 bits of the id; the node itself is read from a lane that holds the
+            // winning key, so larger scenes only lose the tie-break (any pending lane's node is a valid pick).
+            const uint32_t key = done ? 0xFFFFFFFFu : (((63u - sp) << 26) | (cur & 0x03FFFFFFu));
+            const uint32_t kmin = wave_min_u32(key);
+            unode = (uint32_t)__builtin_amdgcn_readlane((int)cur, __builtin_ctzll(__builtin_amdgcn_ballot_w64(key == kmin)));
+        } else if constexpr (kPick == 0) unode = wave_min_u32(done ? 0xFFFFFFFFu : cur);                          // rounds 1-2: smallest id
+        else if constexpr (kPick == 1) unode = ~wave_min_u32(done ? 0xFFFFFFFFu : ~cur);                          // largest id (newest nodes first)
+        else if constexpr (kPick == 2) unode = wave_min_u32(done ? 0xFFFFFFFFu : ((sp << 26) | cur)) & 0x03FFFFFFu;   // shallowest first (ids < 2^26)
+        else unode = 0x03FFFFFFu - (wave_min_u32(done ? 0xFFFFFFFFu : (((63u - sp) << 26) | (0x03FFFFFFu - cur))) & 0x03FFFFFFu);   // deepest first, ties to the larger id
 #else
         const int leader = __builtin_ctzll(pending);
         const uint32_t unode = __builtin_amdgcn_readlane(cur, leader);   // wave-uniform node id
