@@ -807,10 +807,16 @@ void gpu_build_scene(const TriSource& src, uint32_t n, const Box& root, bool ena
     hipLaunchKernelGGL(k_remap_nodes, dim3(grid_for(n_nodes)), dim3(kBlock), 0, st, R);
     HB_TRY(hipMemsetAsync(own_count, 0, sizeof(uint32_t) * ((size_t)n_nodes + 2), st));
     unsigned key_bits = 1; while ((1ull << key_bits) <= (unsigned long long)n_nodes) key_bits++;
+    DevFree sort_tmp;                                                   // only when this bit range needs more than the up-front query said
     if (n) {
         hipLaunchKernelGGL(k_tri_keys, dim3(grid_for(n)), dim3(kBlock), 0, st, R);
-        size_t b = prim_bytes;
-        HB_TRY(rocprim::radix_sort_pairs(prim_tmp, b, key_in, key_out, val_in, val_out, (size_t)n, 0u, key_bits, st));
+        // rocPRIM picks the sort's algorithm (and with it the size of its temporary storage) from the element count AND the bit range, so the need is
+        // asked again for the range actually sorted: the 32-bit query above is a lower bound only (4 M triangles, 23 bits: more).
+        size_t b = 0;
+        HB_TRY(rocprim::radix_sort_pairs(nullptr, b, key_in, key_out, val_in, val_out, (size_t)n, 0u, key_bits, st));
+        void* tmp = prim_tmp;
+        if (b > prim_bytes) { HB_TRY(hipMalloc(&sort_tmp.p, b)); tmp = sort_tmp.p; } else b = prim_bytes;
+        HB_TRY(rocprim::radix_sort_pairs(tmp, b, key_in, key_out, val_in, val_out, (size_t)n, 0u, key_bits, st));
     }
     {
         size_t b = prim_bytes;

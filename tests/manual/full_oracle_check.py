@@ -1,8 +1,8 @@
 """One-off wide check (not a test: minutes of CPU): GPU frames vs the oracle at sizes the test-suite does not reach.
-   python tools/full_oracle_check.py"""
+   python tests/manual/full_oracle_check.py"""
 import importlib, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 rrt = importlib.import_module("rust-ray-tracer_amd"); syn = importlib.import_module("rust-ray-tracer_amd.synthetic")
 from oracle import binding as ob

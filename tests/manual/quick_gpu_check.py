@@ -1,7 +1,7 @@
 """Ad-hoc GPU sanity run: HIP path vs oracle on the teapot at small sizes, then a 1080p timing.  (Not a test; see tests/.)"""
 import importlib, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 rrt = importlib.import_module("rust-ray-tracer_amd")
 from oracle import binding as ob
