@@ -10,7 +10,11 @@
 // 16.16 fixed-point YCbCr->RGB conversion.
 #include <zlib.h>
 
+#include <algorithm>
+#include <array>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "model.hpp"
@@ -87,7 +91,8 @@ struct BitReader {
     void reset_at(const uint8_t* q) { p = q; acc = 0; nbits = 0; hit_marker = false; }
 };
 
-inline int decode_symbol(BitReader& br, const Huff& h) {
+// -1: no code of <= 16 bits matches (a malformed stream -- or a speculative decoder that has not found the code boundaries yet, see entropy_parallel)
+template <class Reader> inline int decode_symbol(Reader& br, const Huff& h) {
     const uint16_t e = h.look[br.peek(Huff::kLook)];
     if (e) { br.skip(e >> 8); return e & 0xFF; }
     int code = 0;
@@ -95,13 +100,43 @@ inline int decode_symbol(BitReader& br, const Huff& h) {
         code = (code << 1) | br.bit();
         if (h.maxcode[len] >= 0 && code <= h.maxcode[len] && code >= h.mincode[len]) return h.vals[h.valptr[len] + code - h.mincode[len]];
     }
-    fail(RRT_ERR_PARSE, "Cannot decode texture file: bad Huffman code");
+    return -1;
 }
 
 inline int extend(int v, int nbits) { return v < (1 << (nbits - 1)) ? v - (1 << nbits) + 1 : v; }
 
 const uint8_t kZigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
                              35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+// One block of the scan: the DC difference and the AC coefficients (natural order) into blk[1..63]; blk[0] is left to the caller, who owns the
+// predictor.  Returns 0, or which rule of an 8-bit baseline stream was broken.
+enum BlockError { kBlockOk = 0, kBadCode, kBadDcCategory, kBadAcRun, kBadAcSize };
+inline const char* block_error_text(int e) {
+    switch (e) {
+        case kBadCode: return "Cannot decode texture file: bad Huffman code";
+        case kBadDcCategory: return "Cannot decode texture file: bad DC category";      // 8-bit JPEG: DC differences have at most 11 bits
+        case kBadAcRun: return "Cannot decode texture file: bad AC run";
+        default: return "Cannot decode texture file: bad AC size";                        // 8-bit JPEG: AC coefficients have at most 10 bits
+    }
+}
+template <class Reader> inline int decode_block(Reader& br, const Huff& dct, const Huff& act, int& dc_diff, int16_t* blk) {
+    const int t = decode_symbol(br, dct);
+    if (t < 0) return kBadCode;
+    if (t > 11) return kBadDcCategory;
+    dc_diff = t ? extend(br.bits(t), t) : 0;
+    for (int k = 1; k < 64;) {
+        const int rs = decode_symbol(br, act);
+        if (rs < 0) return kBadCode;
+        const int r = rs >> 4, sz = rs & 15;
+        if (sz == 0) { if (r == 15) { k += 16; continue; } break; }
+        k += r;
+        if (k > 63) return kBadAcRun;
+        if (sz > 10) return kBadAcSize;
+        blk[kZigzag[k]] = (int16_t)extend(br.bits(sz), sz);
+        k++;
+    }
+    return kBlockOk;
+}
 
 // IJG "islow" inverse DCT: Loeffler-Ligtenberg-Moschytz, CONST_BITS = 13, PASS1_BITS = 2.
 inline int32_t descale(int32_t x, int n) { return (x + (1 << (n - 1))) >> n; }
@@ -139,6 +174,149 @@ void idct_islow(const int32_t in[64], uint8_t* out, size_t stride) {
 }
 
 struct Component { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0; int pred = 0; };
+
+// ---- phase 1 on several threads.  A Huffman stream has no index: where block 20 000 starts is known only after decoding the 19 999 before it.  But a
+// decoder dropped into the middle of the stream -- wrong bit, wrong component, wrong coefficient -- falls into step with the true decode after a few
+// blocks (the codes are short and the end-of-block code keeps re-aligning it), and from the first block START the two share (same bit position, same
+// component) they decode the same thing for ever: the parse has no other state.  So: the scan (stuffed zeros removed) is cut into T byte ranges; decoder
+// i starts at the first bit of range i as if a block of component 0 began there, notes (bit position, component) of every block it starts, and keeps its
+// blocks in a buffer of its own; when all have crossed their range, decoder i runs on into range i + 1 until it starts a block exactly where decoder
+// i + 1 started one.  Decoder 0 is right from its first bit, so by induction everything from each meeting point on is right; what a decoder produced
+// before it was met is dropped.  DC values are differences against a predictor the late starters do not know: they count from 0 and the true value at
+// the meeting point gives the offset.  Anything unexpected -- no meeting inside the next range, a malformed block in a kept stretch, too few blocks, a
+// DC value out of range -- and the function returns false: the caller decodes serially, as before, and reports what it finds.  Same coefficients as the
+// serial decode or no result; the first 1024 x 1024 texture of the teapot scene took 9 ms of one core, the six of them were most of the loader's time.
+struct CleanReader {
+    const uint8_t* base; size_t n_bytes;      // the scan without stuffing; zeros are fed past the end (as the serial reader does at a marker)
+    size_t pos = 0; uint64_t acc = 0; int nbits = 0;
+    void fill() {
+        if (pos + 4 <= n_bytes) { acc = (acc << 32) | ((uint32_t)base[pos] << 24 | (uint32_t)base[pos + 1] << 16 | (uint32_t)base[pos + 2] << 8 | base[pos + 3]); pos += 4; nbits += 32; }
+        else while (nbits <= 32) { acc = (acc << 8) | (pos < n_bytes ? base[pos] : 0); pos++; nbits += 8; }
+    }
+    int peek(int n) { if (nbits < n) fill(); return (int)((acc >> (nbits - n)) & ((1u << n) - 1u)); }
+    void skip(int n) { nbits -= n; }
+    int bit() { const int v = peek(1); skip(1); return v; }
+    int bits(int n) { if (n == 0) return 0; const int v = peek(n); skip(n); return v; }
+    uint64_t bitpos() const { return (uint64_t)pos * 8 - (uint64_t)nbits; }
+};
+
+struct ScanPart {
+    std::vector<int16_t> coef;        // 64 per block, AC filled in; [0] written by the stitch
+    std::vector<int32_t> dc;          // per block: DC with the part's predictors starting from 0
+    std::vector<uint64_t> start;      // per block: bit position << 2 | component
+    std::vector<uint32_t> bad;        // blocks that broke a rule (expected before the part has fallen into step, fatal after)
+    CleanReader br{nullptr, 0}; int comp = 0; int32_t pred[4] = {0, 0, 0, 0};
+    size_t n_main = 0;                // blocks that start inside the part's own range
+    bool met = false; size_t met_at = 0, met_next = 0; int32_t pred_at_meeting[4] = {0, 0, 0, 0};
+    void one_block(const Huff* const* dct, const Huff* const* act, int nc) {
+        const size_t b = start.size();
+        start.push_back((br.bitpos() << 2) | (uint64_t)comp);
+        coef.resize((b + 1) * 64, 0);
+        int diff = 0;
+        const int e = decode_block(br, *dct[comp], *act[comp], diff, &coef[b * 64]);
+        if (e) { bad.push_back((uint32_t)b); dc.push_back(0); comp = 0; return; }      // (out of step: try again from here as component 0)
+        pred[comp] += diff; dc.push_back(pred[comp]);
+        comp = comp + 1 == nc ? 0 : comp + 1;
+    }
+};
+
+bool entropy_parallel(const uint8_t* scan, const uint8_t* end, const std::vector<Component>& comps, const Huff* dc_tab, const Huff* ac_tab, size_t n_total /* blocks x components */,
+                      std::vector<ScanPart>& parts, std::vector<const int16_t*>& block_ptr) {
+    const int nc = (int)comps.size();
+    const bool trace = std::getenv("RRT_SETUP_TRACE") != nullptr;
+    auto lap = [&, last = std::chrono::steady_clock::now()](const char* what) mutable {
+        if (!trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[jpeg entropy] %-28s %7.3f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count()); last = now;
+    };
+    // the scan up to its first marker, stuffing removed
+    std::vector<uint8_t> clean; clean.reserve((size_t)(end - scan));
+    for (const uint8_t* q = scan; q < end;) {
+        const uint8_t* f = (const uint8_t*)std::memchr(q, 0xFF, (size_t)(end - q));
+        if (!f) { clean.insert(clean.end(), q, end); break; }
+        clean.insert(clean.end(), q, f);
+        if (f + 1 < end && f[1] == 0) { clean.push_back(0xFF); q = f + 2; } else break;   // a marker (or a lone 0xFF at the end of the file): the scan ends here
+    }
+    lap("stuffing removed");
+    const size_t nb = clean.size();
+    size_t part_bytes = 48u << 10;                                                      // below this a part is not worth its thread
+    if (const char* e = std::getenv("RRT_JPEG_PART_BYTES")) part_bytes = std::max<size_t>(8, (size_t)std::atoll(e));   // (tests: the stitching on small files)
+    const size_t T = std::min<size_t>({(size_t)host_threads(), (size_t)16, nb / part_bytes});
+    if (T < 2 || n_total >= (1ull << 32) || nb >= (1ull << 40)) return false;
+    const Huff* dct[4]; const Huff* act[4];
+    for (int c = 0; c < nc; c++) { dct[c] = &dc_tab[comps[c].td]; act[c] = &ac_tab[comps[c].ta]; }
+    parts.assign(T, ScanPart{});
+    auto part_end_bit = [&](size_t i) { return (uint64_t)(i + 1 == T ? nb : nb * (i + 1) / T) * 8; };
+    parallel_ranges(T, 1, [&](size_t b, size_t e, size_t) {
+        for (size_t i = b; i < e; i++) {
+            ScanPart& P = parts[i];
+            P.br = CleanReader{clean.data(), nb}; P.br.pos = nb * i / T;
+            const size_t guess = n_total / T + n_total / (4 * T) + 64;
+            P.coef.reserve(guess * 64); P.dc.reserve(guess); P.start.reserve(guess);
+            const uint64_t stop = part_end_bit(i);
+            while (P.br.bitpos() < stop && P.start.size() < n_total + 8) P.one_block(dct, act, nc);
+            P.n_main = P.start.size();
+        }
+    });
+    lap("parts decoded");
+    parallel_ranges(T - 1, 1, [&](size_t b, size_t e, size_t) {
+        for (size_t i = b; i < e; i++) {
+            ScanPart& P = parts[i]; const ScanPart& N = parts[i + 1];
+            size_t r = 0;
+            for (;;) {
+                const uint64_t key = (P.br.bitpos() << 2) | (uint64_t)P.comp;
+                while (r < N.n_main && (N.start[r] >> 2) < (key >> 2)) r++;
+                if (r >= N.n_main) break;                                            // crossed the whole next range without meeting its decoder
+                if (N.start[r] == key) { P.met = true; P.met_at = P.start.size(); P.met_next = r; std::memcpy(P.pred_at_meeting, P.pred, sizeof P.pred); break; }
+                P.one_block(dct, act, nc);
+            }
+        }
+    });
+    lap("run-on until met");
+    // stitch: global number of each part's block 0, first kept block, predictor offsets
+    std::vector<int64_t> first_global(T, 0); std::vector<size_t> keep_from(T, 0), keep_to(T, 0);
+    std::vector<std::array<int64_t, 4>> offset(T, std::array<int64_t, 4>{0, 0, 0, 0});
+    for (size_t i = 0; i + 1 < T; i++) {
+        const ScanPart& P = parts[i]; const ScanPart& N = parts[i + 1];
+        if (!P.met || P.met_at < keep_from[i]) return false;
+        keep_to[i] = P.met_at; keep_from[i + 1] = P.met_next;
+        first_global[i + 1] = first_global[i] + (int64_t)P.met_at - (int64_t)P.met_next;
+        const int64_t g = first_global[i] + (int64_t)P.met_at;
+        if (g < 0 || (int)(g % nc) != (int)(N.start[P.met_next] & 3u)) return false;
+        for (int c = 0; c < nc; c++) {
+            int64_t local = 0;                                                       // the next part's own predictor of component c when it started the meeting block
+            for (size_t k = P.met_next; k-- > 0;) if ((int)(N.start[k] & 3u) == c && !std::binary_search(N.bad.begin(), N.bad.end(), (uint32_t)k)) { local = N.dc[k]; break; }
+            offset[i + 1][c] = (int64_t)P.pred_at_meeting[c] + offset[i][c] - local;
+        }
+    }
+    keep_to[T - 1] = parts[T - 1].start.size();
+    if (first_global[T - 1] + (int64_t)keep_to[T - 1] < (int64_t)n_total) return false;   // a truncated scan: the serial decode feeds zeros and reports nothing -- let it
+    block_ptr.assign(n_total, nullptr);
+    std::vector<char> ok(T, 1);
+    parallel_ranges(T, 1, [&](size_t b, size_t e, size_t) {
+        for (size_t i = b; i < e; i++) {
+            ScanPart& P = parts[i];
+            for (size_t k = keep_from[i]; k < keep_to[i]; k++) {
+                const int64_t g = first_global[i] + (int64_t)k;
+                if (g >= (int64_t)n_total) break;
+                const int c = (int)(P.start[k] & 3u);
+                const int64_t v = (int64_t)P.dc[k] + offset[i][c];
+                if (g < 0 || (int)(g % nc) != c || v < -32768 || v > 32767) { ok[i] = 0; break; }
+                P.coef[k * 64] = (int16_t)v; block_ptr[(size_t)g] = &P.coef[k * 64];
+            }
+            for (uint32_t k : P.bad) if (k >= keep_from[i] && k < keep_to[i] && first_global[i] + (int64_t)k < (int64_t)n_total) ok[i] = 0;
+        }
+    });
+    for (size_t i = 0; i < T; i++) if (!ok[i]) return false;
+    for (size_t g = 0; g < n_total; g++) if (!block_ptr[g]) return false;
+    if (trace) {
+        size_t extra = 0, dropped = 0;
+        for (size_t i = 0; i < T; i++) { extra += parts[i].start.size() - parts[i].n_main; dropped += keep_from[i]; }
+        lap("stitched");
+        fprintf(stderr, "[jpeg entropy] %zu parts, %zu blocks: %zu decoded twice (run-on), %zu dropped (out of step)\n", T, n_total, extra, dropped);
+    }
+    return true;
+}
 
 void decode_jpeg(const std::vector<uint8_t>& buf, std::vector<uint8_t>& out, uint32_t& W, uint32_t& H, uint32_t& channels) {
     const uint8_t* p = buf.data(); const uint8_t* end = p + buf.size();
@@ -211,48 +389,48 @@ void decode_jpeg(const std::vector<uint8_t>& buf, std::vector<uint8_t>& out, uin
 
     const uint32_t bw = (W + 7) / 8, bh = (H + 7) / 8;
     const size_t stride = (size_t)bw * 8;
-    // ---- phase 1, sequential by nature: the entropy-coded segment -> quantised coefficients (natural order) of every block of every component
+    // ---- phase 1: the entropy-coded segment -> quantised coefficients (natural order) of every block of every component.  On several threads when the
+    // scan is long and has no restart markers (entropy_parallel above); one block after the other otherwise, and whenever that attempt declines.
     const size_t n_blocks = (size_t)bw * bh, nc = comps.size();
-    std::vector<int16_t> coef(n_blocks * nc * 64, 0);
-    BitReader br{p, end};
-    int to_restart = restart_interval;
-    for (uint32_t by = 0; by < bh; by++) {
-        for (uint32_t bx = 0; bx < bw; bx++) {
-            if (restart_interval && to_restart == 0) {
-                // byte-align, expect RSTn (the reader never passes a marker: it is at or ahead of br.p)
-                const uint8_t* q = br.p;
-                while (q + 1 < end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) q++;
-                if (q + 1 >= end) fail(RRT_ERR_PARSE, "Cannot decode texture file: missing RST");
-                br.reset_at(q + 2);
-                for (auto& c : comps) c.pred = 0;
-                to_restart = restart_interval;
-            }
-            for (size_t ci = 0; ci < nc; ci++) {
-                Component& c = comps[ci];
-                int16_t* blk = &coef[(((size_t)by * bw + bx) * nc + ci) * 64];
-                int t = decode_symbol(br, dc[c.td]);
-                if (t > 11) fail(RRT_ERR_PARSE, "Cannot decode texture file: bad DC category");          // 8-bit JPEG: DC differences have at most 11 bits
-                int diff = t ? extend(br.bits(t), t) : 0;
-                c.pred += diff;
-                if (c.pred < -32768 || c.pred > 32767) fail(RRT_ERR_PARSE, "Cannot decode texture file: DC predictor out of range");
-                blk[0] = (int16_t)c.pred;
-                for (int k = 1; k < 64;) {
-                    int rs = decode_symbol(br, ac[c.ta]);
-                    int r = rs >> 4, sz = rs & 15;
-                    if (sz == 0) { if (r == 15) { k += 16; continue; } break; }
-                    k += r;
-                    if (k > 63) fail(RRT_ERR_PARSE, "Cannot decode texture file: bad AC run");
-                    if (sz > 10) fail(RRT_ERR_PARSE, "Cannot decode texture file: bad AC size");                // 8-bit JPEG: AC coefficients have at most 10 bits
-                    blk[kZigzag[k]] = (int16_t)extend(br.bits(sz), sz);
-                    k++;
+    const bool trace = std::getenv("RRT_SETUP_TRACE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    std::vector<int16_t> coef; std::vector<ScanPart> parts; std::vector<const int16_t*> block_ptr;
+    const bool in_parallel = !restart_interval && !std::getenv("RRT_JPEG_SERIAL") && entropy_parallel(p, end, comps, dc, ac, n_blocks * nc, parts, block_ptr);
+    if (!in_parallel) {
+        parts.clear();
+        coef.assign(n_blocks * nc * 64, 0);
+        block_ptr.resize(n_blocks * nc);
+        for (size_t g = 0; g < n_blocks * nc; g++) block_ptr[g] = &coef[g * 64];
+        BitReader br{p, end};
+        int to_restart = restart_interval;
+        for (uint32_t by = 0; by < bh; by++) {
+            for (uint32_t bx = 0; bx < bw; bx++) {
+                if (restart_interval && to_restart == 0) {
+                    // byte-align, expect RSTn (the reader never passes a marker: it is at or ahead of br.p)
+                    const uint8_t* q = br.p;
+                    while (q + 1 < end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) q++;
+                    if (q + 1 >= end) fail(RRT_ERR_PARSE, "Cannot decode texture file: missing RST");
+                    br.reset_at(q + 2);
+                    for (auto& c : comps) c.pred = 0;
+                    to_restart = restart_interval;
                 }
+                for (size_t ci = 0; ci < nc; ci++) {
+                    Component& c = comps[ci];
+                    int16_t* blk = &coef[(((size_t)by * bw + bx) * nc + ci) * 64];
+                    int diff = 0;
+                    if (const int e = decode_block(br, dc[c.td], ac[c.ta], diff, blk)) fail(RRT_ERR_PARSE, block_error_text(e));
+                    c.pred += diff;
+                    if (c.pred < -32768 || c.pred > 32767) fail(RRT_ERR_PARSE, "Cannot decode texture file: DC predictor out of range");
+                    blk[0] = (int16_t)c.pred;
+                }
+                if (restart_interval) to_restart--;
             }
-            if (restart_interval) to_restart--;
         }
     }
 
     // ---- phase 2, every row of blocks on its own: dequantise, inverse DCT, colour conversion (a 1024 x 1024 texture: 3 x 16 384 blocks -- the larger
     // part of the decode, and the part the host's cores can share)
+    const auto t_entropy = std::chrono::steady_clock::now();
     const bool grey = nc == 1;
     channels = grey ? 1 : 3; out.resize((size_t)W * H * channels);
     const bool ycc = adobe_transform < 0 ? !(!grey && comps[0].id == 'R' && comps[1].id == 'G' && comps[2].id == 'B') : adobe_transform != 0;
@@ -263,7 +441,7 @@ void decode_jpeg(const std::vector<uint8_t>& buf, std::vector<uint8_t>& out, uin
         for (size_t by = rb; by < re; by++) {
             for (uint32_t bx = 0; bx < bw; bx++)
                 for (size_t ci = 0; ci < nc; ci++) {
-                    const int16_t* q = &coef[((by * bw + bx) * nc + ci) * 64];
+                    const int16_t* q = block_ptr[(by * bw + bx) * nc + ci];
                     const uint16_t* t = qt[comps[ci].tq];
                     int32_t blk[64];
                     for (int k = 0; k < 64; k++) { const int32_t v = (int32_t)q[k] * t[k]; blk[k] = v < -(1 << 15) ? -(1 << 15) : v > (1 << 15) ? (1 << 15) : v; }   // hostile tables: keep the IDCT inside int32 (a valid file never gets near)
@@ -287,6 +465,11 @@ void decode_jpeg(const std::vector<uint8_t>& buf, std::vector<uint8_t>& out, uin
             }
         }
     });
+    if (trace) {
+        const auto t_end = std::chrono::steady_clock::now();
+        fprintf(stderr, "[jpeg] %u x %u, %zu bytes: entropy decode %.2f ms (%zu threads), dequantise + IDCT + colour %.2f ms\n", W, H, buf.size(),
+                std::chrono::duration<double, std::milli>(t_entropy - t_begin).count(), in_parallel ? parts.size() : (size_t)1, std::chrono::duration<double, std::milli>(t_end - t_entropy).count());
+    }
 }
 
 // ===================================================================== PNG

@@ -180,6 +180,47 @@ def test_jpeg_decoder_on_synthetic_files(rrt, tmp_path):
             assert e2.status in (rrt.ERR_PARSE, rrt.ERR_UNSUPPORTED)
 
 
+def test_jpeg_entropy_decode_on_several_threads(rrt, tmp_path, monkeypatch):
+    """Phase 1 of the decoder cut into parts that find the block boundaries by themselves (image_decode.cpp: entropy_parallel): same texels as the
+    one-thread decode and as libjpeg whatever the number of parts, also when the parts are a few dozen bytes long (most of a part out of step,
+    blocks longer than a part, no meeting -> serial fallback), for truncated files (fallback: zeros fed like libjpeg) and with restart markers (serial)."""
+    Image = pytest.importorskip("PIL.Image")
+    for name in ["wood_normal.jpg", "metal_normal.jpg"]:
+        path = os.path.join(ASSETS, name)
+        monkeypatch.setenv("RRT_JPEG_SERIAL", "1"); want = rrt.decode_image_file(path); monkeypatch.delenv("RRT_JPEG_SERIAL")
+        for threads, part in (("2", None), ("5", None), ("16", None), ("16", "3000"), ("7", "100")):
+            monkeypatch.setenv("RRT_HOST_THREADS", threads)
+            if part: monkeypatch.setenv("RRT_JPEG_PART_BYTES", part)
+            assert np.array_equal(rrt.decode_image_file(path), want), (name, threads, part)
+            monkeypatch.delenv("RRT_JPEG_PART_BYTES", raising=False)
+    rng = np.random.default_rng(11)
+    smooth = np.clip(np.cumsum(rng.normal(size=(203, 331, 3)), axis=1) * 6 + 128, 0, 255).astype(np.uint8)
+    noise = rng.integers(0, 256, (120, 96, 3), dtype=np.uint8)
+    flat = np.full((64, 640, 3), 77, np.uint8); flat[:, 300:310] = noise[:64, :10]              # long runs of two-bit blocks around a busy stripe
+    files = []
+    for k, img in enumerate((smooth, noise, flat, noise[:9, :17])):
+        for q in (5, 60, 100):
+            p = tmp_path / f"p{k}_{q}.jpg"; Image.fromarray(img).save(p, quality=q, subsampling=0); files.append(p)
+    p = tmp_path / "rst.jpg"
+    try:
+        Image.fromarray(smooth).save(p, quality=90, subsampling=0, restart_marker_blocks=5); files.append(p)
+    except TypeError:
+        pass
+    monkeypatch.setenv("RRT_HOST_THREADS", "16")
+    for p in files:
+        ref = np.asarray(Image.open(p).convert("RGB"))
+        for part in ("16", "64", "700", "20000"):
+            monkeypatch.setenv("RRT_JPEG_PART_BYTES", part)
+            assert np.array_equal(rrt.decode_image_file(str(p)), ref), (p.name, part)
+    data = open(files[1], "rb").read()
+    for cut in (len(data) // 3, len(data) // 2, len(data) - 3, len(data) - 40):
+        t = tmp_path / "cut.jpg"; t.write_bytes(data[:cut])
+        monkeypatch.setenv("RRT_JPEG_SERIAL", "1"); want = rrt.decode_image_file(str(t)); monkeypatch.delenv("RRT_JPEG_SERIAL")
+        for part in ("16", "300"):
+            monkeypatch.setenv("RRT_JPEG_PART_BYTES", part)
+            assert np.array_equal(rrt.decode_image_file(str(t)), want), (cut, part)
+
+
 def test_png_decoder(rrt, tmp_path):
     Image = pytest.importorskip("PIL.Image")
     rng = np.random.default_rng(1)
