@@ -239,9 +239,9 @@ bool entropy_parallel(const uint8_t* scan, const uint8_t* end, const std::vector
     }
     lap("stuffing removed");
     const size_t nb = clean.size();
-    size_t part_bytes = 48u << 10;                                                      // below this a part is not worth its thread
+    size_t part_bytes = 24u << 10;                                                      // below this a part is not worth its thread
     if (const char* e = std::getenv("RRT_JPEG_PART_BYTES")) part_bytes = std::max<size_t>(8, (size_t)std::atoll(e));   // (tests: the stitching on small files)
-    const size_t T = std::min<size_t>({(size_t)host_threads(), (size_t)16, nb / part_bytes});
+    const size_t T = std::min<size_t>({(size_t)host_threads(), (size_t)24, nb / part_bytes});
     if (T < 2 || n_total >= (1ull << 32) || nb >= (1ull << 40)) return false;
     const Huff* dct[4]; const Huff* act[4];
     for (int c = 0; c < nc; c++) { dct[c] = &dc_tab[comps[c].td]; act[c] = &ac_tab[comps[c].ta]; }

@@ -612,15 +612,10 @@ StagingRing& ring_of_current_device() {                                 // (call
     g_rings[dev].ensure();
     return g_rings[dev];
 }
-// parallel memcpy on a few short-lived workers (copies out of the ring on the frame path: thread start-up is ~20 us against megabytes)
+// parallel memcpy on the host pool (copies out of the ring on the frame path: one core moves ~10 GB/s)
 void copy_bytes(char* dst, const char* src, size_t len) {
-    const unsigned workers = std::max(1u, std::min(host_threads(), 4u));
-    if (workers > 1 && len >= ((size_t)2 << 20)) {
-        std::vector<std::thread> th;
-        for (unsigned w = 1; w < workers; w++) th.emplace_back([=] { const size_t b = len * w / workers, e = len * (w + 1) / workers; std::memcpy(dst + b, src + b, e - b); });
-        std::memcpy(dst, src, len / workers);
-        for (auto& t : th) t.join();
-    } else std::memcpy(dst, src, len);
+    if (len < ((size_t)2 << 20)) { std::memcpy(dst, src, len); return; }
+    parallel_ranges(len, (len + 3) / 4, [&](size_t b, size_t e, size_t) { std::memcpy(dst + b, src + b, e - b); });
 }
 
 }  // namespace
@@ -641,7 +636,7 @@ void staged_upload(void* dst, const void* src, size_t bytes, void* stream_) {
     std::lock_guard<std::mutex> lk(g_ring_mu);
     StagingRing& R = ring_of_current_device();
     const size_t S = StagingRing::kSlotBytes, n_chunks = (bytes + S - 1) / S;
-    // One worker per ring slot, each an independent pipeline: wait for the slot's last DMA, fill the slot from `src`, enqueue its DMA, take the next
+    // One task per ring slot (host pool), each an independent pipeline: wait for the slot's last DMA, fill the slot from `src`, enqueue its DMA, take the next
     // chunk -- so the copies into page-locked memory (the slow part: one core moves ~10 GB/s) run on several cores while the DMA engine drains
     // the finished slots.  Chunks land at disjoint destinations: their order on the stream does not matter.
     const unsigned workers = (unsigned)std::min<size_t>(std::min<size_t>(StagingRing::kSlots, n_chunks), host_threads());
@@ -650,7 +645,7 @@ void staged_upload(void* dst, const void* src, size_t bytes, void* stream_) {
     std::atomic<size_t> next_chunk{0};
     std::vector<int> err(workers, 0);
     auto run = [&](unsigned w) {
-        if (w && hipSetDevice(dev) != hipSuccess) { err[w] = (int)hipGetLastError(); return; }   // (HIP's current device is per thread)
+        if (hipSetDevice(dev) != hipSuccess) { err[w] = (int)hipGetLastError(); return; }        // (HIP's current device is per thread, and a pool worker keeps its last one)
         char* stage = R.mem + (size_t)w * S;
         for (size_t c; (c = next_chunk.fetch_add(1)) < n_chunks;) {
             const size_t off = c * S, len = std::min(S, bytes - off);
@@ -661,10 +656,7 @@ void staged_upload(void* dst, const void* src, size_t bytes, void* stream_) {
             if (e != hipSuccess) { err[w] = (int)e; return; }
         }
     };
-    std::vector<std::thread> th;
-    for (unsigned w = 1; w < workers; w++) th.emplace_back(run, w);
-    run(0);
-    for (auto& t : th) t.join();
+    parallel_ranges(workers, 1, [&](size_t b, size_t e, size_t) { for (size_t w = b; w < e; w++) run((unsigned)w); });
     for (int e : err) if (e) throw HipBuildFail{e, "staged_upload (pinned-staging host-to-device copy)"};
     // src has been read completely: it may be freed.  dst is complete once `stream` has drained; the slots guard themselves (busy + event).
 }
