@@ -8,6 +8,8 @@
 #include <cmath>
 #include <cstring>
 #include <fstream>
+#include <memory>
+#include <unordered_map>
 #include <optional>
 #include <sstream>
 #include <string_view>
@@ -91,17 +93,47 @@ std::string read_file(const std::string& path) {   // fs::read_to_string, main.r
 }
 
 // str::lines(): split on '\n', drop one trailing '\r'
-template <class F> void for_each_line(const std::string& text, F&& fn) {
+template <class F> void for_each_line(sv text, F&& fn) {
     size_t i = 0;
     while (i < text.size()) {
         size_t j = text.find('\n', i);
-        if (j == std::string::npos) j = text.size();
+        if (j == sv::npos) j = text.size();
         sv line(text.data() + i, j - i);
         if (!line.empty() && line.back() == '\r') line.remove_suffix(1);
         fn(line);
         i = j + 1;
     }
 }
+
+// Texture decode started before the .obj text is tokenised.  The reference decodes a texture where its "map_Ka"/"bump" line stands, which is inside the
+// "mtllib" directive, which stands among the first lines of the file -- but the directive is only executed (in file order, with everything before
+// it) after the tokeniser has been over the whole text.  The six JPEGs of the teapot's materials take as long as that, so: the head of the text is
+// searched for an "mtllib" line, the files named by "map_Ka"/"bump" lines of that .mtl are decoded on the host pool meanwhile, and when the directive
+// is executed for real, a texture whose file is already decoded is taken from here.  Only successful decodes are kept (same bytes as a decode on the
+// spot); everything that can fail fails where and when it did before.
+struct TexturePrefetch {
+    struct Image { std::vector<uint8_t> bytes; uint32_t w = 0, h = 0, ch = 0; };
+    std::mutex mu; std::condition_variable cv; bool done = false;
+    std::unordered_map<std::string, Image> images;                        // by path
+    static std::shared_ptr<TexturePrefetch> start(const std::string& dir, sv head);
+    // Called on the loader's own thread, never from a range running on the pool: a pool thread that waits here may, while helping, have been handed
+    // this very prefetch's task further down its stack, and would wait for itself (parallel.hpp: a task waits for its own children only).
+    void wait() {
+        for (;;) {
+            { std::lock_guard<std::mutex> g(mu); if (done) return; }
+            if (HostPool::get().run_one()) continue;
+            std::unique_lock<std::mutex> lk(mu);
+            if (!done) cv.wait_for(lk, std::chrono::microseconds(200));
+        }
+    }
+    bool take(const std::string& path, Image& out) {                     // after wait()
+        std::lock_guard<std::mutex> g(mu);
+        auto it = images.find(path);
+        if (it == images.end()) return false;
+        out = std::move(it->second); images.erase(it);
+        return true;
+    }
+};
 
 struct Loader {
     std::string dir;
@@ -112,6 +144,7 @@ struct Loader {
     // reserves the texture's index and the files of one .mtl are decoded together afterwards, one worker per file (six 1024x1024 JPEGs are
     // most of the teapot's set-up time).  A decode failure is still reported in line order: before any later failure of the .mtl text.
     std::vector<std::pair<uint32_t, std::string>> pending_textures;
+    std::shared_ptr<TexturePrefetch> prefetch;
     uint32_t load_texture(const std::string& name) {
         m.textures.emplace_back();
         pending_textures.emplace_back((uint32_t)m.textures.size() - 1, name);
@@ -121,10 +154,13 @@ struct Loader {
         const auto t0 = std::chrono::steady_clock::now();
         std::vector<std::pair<uint32_t, std::string>> work;
         work.swap(pending_textures);
+        if (prefetch) prefetch->wait();
         parallel_ranges(work.size(), 1, [&](size_t b, size_t e, size_t) {
             for (size_t i = b; i < e; i++) {
                 std::vector<uint8_t> bytes; uint32_t w = 0, h = 0, ch = 0;
-                decode_image_file(dir + work[i].second, bytes, w, h, ch);
+                TexturePrefetch::Image ready;
+                if (prefetch && prefetch->take(dir + work[i].second, ready)) { bytes = std::move(ready.bytes); w = ready.w; h = ready.h; ch = ready.ch; }
+                else decode_image_file(dir + work[i].second, bytes, w, h, ch);
                 // utils.rs:353 walks `as_bytes().chunks(3)` whatever the colour type; only a 3-byte-per-pixel buffer gives
                 // width*height colours, anything else indexes out of bounds later (raytracer.rs:55).  Refuse it here.
                 if (ch != 3) fail(RRT_ERR_UNSUPPORTED, "texture '" + work[i].second + "' is not 3 bytes per pixel");
@@ -266,7 +302,7 @@ struct Loader {
 
     void parse_obj(sv text) {
         // (1)
-        const size_t want = std::max<size_t>(1, std::min<size_t>(host_threads(), text.size() / (4u << 20)));
+        const size_t want = std::max<size_t>(1, std::min<size_t>(host_threads(), text.size() / (512u << 10)));   // (host pool: a range costs microseconds, a megabyte of text ~1 ms)
         std::vector<size_t> cut{0};
         for (size_t p = 1; p < want; p++) {
             size_t at = text.find('\n', std::max(cut.back(), text.size() * p / want));
@@ -318,7 +354,7 @@ struct Loader {
         if (trace) fprintf(stderr, "[loader] walk %.1f ms\n", since(tA));
         tA = now();
         // all "v"/"vt"/"vn" values stay where the tokeniser put them: value number i (file order) is element i - off[c] of chunk c's array, c found by
-        // binary search over the chunk offsets (<= 32 chunks).  (Round 2 concatenated them first: 216 MB of copies, 30 ms of the 1 M soup's 75 ms parse.)
+        // binary search over the chunk offsets (<= 128 chunks).  (Round 2 concatenated them first: 216 MB of copies, 30 ms of the 1 M soup's 75 ms parse.)
         auto chunk_of = [&](const std::vector<size_t>& off, uint64_t i) { return (size_t)(std::upper_bound(off.begin(), off.end(), (size_t)i) - off.begin()) - 1; };
         // the faces before the first failing directive, each against the counts of its own line (get_triangle, utils.rs:253-343)
         m.triangles.resize_uninit(stop_face);
@@ -349,12 +385,48 @@ struct Loader {
     struct FaceError { size_t face; Error err; };
 };
 
+std::shared_ptr<TexturePrefetch> TexturePrefetch::start(const std::string& dir, sv head) {
+    std::string mtl;
+    for_each_line(head.substr(0, std::min<size_t>(head.size(), 1u << 16)), [&](sv line) {
+        if (!mtl.empty()) return;
+        Tokens t{line};
+        auto type = t.next();
+        if (type && *type == "mtllib") if (auto nm = t.next()) mtl = std::string(*nm);
+    });
+    if (mtl.empty() || host_threads() < 2) return nullptr;
+    auto self = std::make_shared<TexturePrefetch>();
+    HostPool::get().submit([self, dir, mtl] {
+        try {
+            const std::string text = read_file(dir + mtl);
+            std::vector<std::string> names;
+            for_each_line(text, [&](sv line) {
+                Tokens t{line};
+                auto type = t.next();
+                if (!type || !(*type == "map_Ka" || *type == "bump")) return;
+                if (auto nm = t.next()) if (std::find(names.begin(), names.end(), std::string(*nm)) == names.end()) names.emplace_back(*nm);
+            });
+            std::vector<Image> got(names.size());
+            parallel_ranges(names.size(), 1, [&](size_t b, size_t e, size_t) {
+                for (size_t i = b; i < e; i++) {
+                    try { decode_image_file(dir + names[i], got[i].bytes, got[i].w, got[i].h, got[i].ch); }
+                    catch (...) { got[i] = Image{}; }                     // not kept: the directive decodes it again and reports what is wrong with it
+                }
+            });
+            std::lock_guard<std::mutex> g(self->mu);
+            for (size_t i = 0; i < names.size(); i++) if (!got[i].bytes.empty()) self->images.emplace(dir + names[i], std::move(got[i]));
+        } catch (...) {}
+        { std::lock_guard<std::mutex> g(self->mu); self->done = true; }
+        self->cv.notify_all();
+    });
+    return self;
+}
+
 }  // namespace
 
 void load_obj(const std::string& obj_path, const Box& root, Model& out) {
     out.root = root;                       // (out is a freshly constructed Model: rrt_model_load_obj)
     size_t slash = obj_path.find_last_of('/');
-    Loader L{slash == std::string::npos ? std::string() : obj_path.substr(0, slash + 1), out, {}, {}};
+    Loader L{slash == std::string::npos ? std::string() : obj_path.substr(0, slash + 1), out, {}, {}, nullptr};
     using clk = std::chrono::steady_clock;
     auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const auto t0 = clk::now();
@@ -373,6 +445,7 @@ void load_obj(const std::string& obj_path, const Box& root, Model& out) {
         map.p = static_cast<const char*>(q);
     }
     const auto t1 = clk::now();
+    L.prefetch = TexturePrefetch::start(L.dir, sv(map.p ? map.p : "", map.n));
     try { L.parse_obj(sv(map.p ? map.p : "", map.n)); }
     catch (const Loader::FaceError& fe) { throw fe.err; }
     const auto t2 = clk::now();

@@ -26,7 +26,7 @@ namespace rrt {
 inline unsigned host_threads() {
     if (const char* e = std::getenv("RRT_HOST_THREADS")) { const int v = std::atoi(e); if (v >= 1) return (unsigned)std::min(v, 256); }
     const unsigned hc = std::thread::hardware_concurrency();
-    return std::max(1u, std::min(hc ? hc : 1u, 32u));
+    return std::max(1u, std::min(hc ? hc : 1u, 128u));     // (the 1 M-triangle .obj, 253 MB of text: 32 ranges 22 ms, 128 ranges 6 ms on a 256-thread host)
 }
 
 class HostPool {
@@ -37,7 +37,7 @@ public:
         {
             std::lock_guard<std::mutex> g(m_);
             q_.push_back(std::move(task));
-            if (idle_ == 0 && n_workers_ < cap_) { n_workers_++; spawn = true; }
+            if (q_.size() > idle_ && n_workers_ < cap_) { n_workers_++; spawn = true; }   // (idle workers that have not woken yet are still counted: one each)
         }
         if (spawn) {
             try { std::thread([this] { work(); }).detach(); }
@@ -79,7 +79,9 @@ private:
 };
 
 // f(begin, end, part) on `parts` contiguous ranges of [0, n); parts <= host_threads().  An exception of the EARLIEST range that threw is rethrown.
-// The ranges of one call may run in any order and not all at once: they must not wait for one another.
+// The ranges of one call may run in any order and not all at once: they must not wait for one another.  More generally, nothing that runs on the pool may
+// wait for anything but its own nested parallel_ranges: a waiting thread helps with whatever is queued, so the task it waits for may be the one further
+// down its own stack.  For the same reason no lock that a queued task could want is held across a call.
 template <class F> void parallel_ranges(size_t n, size_t min_per_part, F&& f) {
     const size_t parts = std::max<size_t>(1, std::min<size_t>(host_threads(), min_per_part ? n / min_per_part : n));
     if (parts <= 1 || n == 0) { f((size_t)0, n, (size_t)0); return; }

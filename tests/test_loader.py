@@ -221,6 +221,33 @@ def test_jpeg_entropy_decode_on_several_threads(rrt, tmp_path, monkeypatch):
             assert np.array_equal(rrt.decode_image_file(str(t)), want), (cut, part)
 
 
+@pytest.mark.timeout(240)
+def test_concurrent_loads_share_the_host_pool(rrt):
+    """Several threads inside rrt_model_load_obj at once (ctypes drops the GIL): nested parallel ranges -- loader > texture prefetch > decoder > parts --
+    all on the one host pool, whose waiting threads help with whatever is queued.  Must neither deadlock nor mix results up."""
+    import threading
+    want = {n: rrt.parse_obj_file(os.path.join(ASSETS, n)) for n in ("model2.obj", "model3.obj", "model.obj")}
+    ref = {n: (sd.triangles()[0].copy(), [t.copy() for t in sd.textures()]) for n, sd in want.items()}
+    errors = []
+
+    def worker(k):
+        try:
+            for rep in range(3):
+                n = ("model2.obj", "model3.obj", "model.obj")[(k + rep) % 3]
+                sd = rrt.parse_obj_file(os.path.join(ASSETS, n))
+                assert np.array_equal(sd.triangles()[0], ref[n][0])
+                for a, b in zip(sd.textures(), ref[n][1]):
+                    assert np.array_equal(a, b)
+        except Exception as e:                                          # noqa: BLE001 (reported below, from the main thread)
+            errors.append((k, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(5)]
+    for t in th: t.start()
+    for t in th: t.join(200)
+    assert not any(t.is_alive() for t in th), "a load is stuck"
+    assert not errors, errors
+
+
 def test_png_decoder(rrt, tmp_path):
     Image = pytest.importorskip("PIL.Image")
     rng = np.random.default_rng(1)
