@@ -575,7 +575,9 @@ def main() -> None:
                     "hbm": {"algorithmic_bytes_per_launch": hbm_bytes, "achieved": round(hbm_bytes / (kernel_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBPS,
                             "unit": "GB/s", "frac": round(hbm_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6),
                             "measured_bytes_per_launch": traffic, "measured_over_algorithmic": round(traffic / hbm_bytes, 2) if traffic else None,
-                            "note": "algorithmic = scene (uploaded once, L2/MALL resident) + framebuffer; the path is not HBM-bound"}}
+                            "note": "algorithmic = scene (uploaded once, L2/MALL resident) + framebuffer; the path is not HBM-bound.  The excess over it is write traffic: a wave covers 4x4 pixels and stores four "
+                                    "16-byte row segments (quarter lines), plus the reflection stack in scratch; an 8x2 footprint (32-byte segments) was measured: +1 % frame time on the teapot, "
+                                    "nothing on the soups (profiles/r03_ab_wave_footprint.txt) -- not adopted"}}
         if counters is not None:
             # what the REFERENCE's algorithm does for this frame (every triangle of every visited node's list tested, every child box slab-tested);
             # the kernel reaches the same pixels while skipping most of it (result-preserving index), so this is a work ratio, not a utilisation

@@ -732,6 +732,9 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
         // ever need it, instead of early with few lanes and again for the late-comers (rounds 1-2 took the smallest id, a breadth-first-like order:
         // 17.8 of 64 lanes per visit on the 100 k soup).  Any order gives the same per-lane results.  100 k soup 11.8 -> 8.9 ms, 1 M soup 26.0 -> 22.9 ms,
         // teapot 0.894 -> 0.882 ms (profiles/r03_ab_pick_policy.txt; largest id first: 8.95 / 23.5; shallowest first: 11.87 / 26.06).
+#ifndef RRT_WAVE_FOOTPRINT
+#define RRT_WAVE_FOOTPRINT 0
+#endif
 #ifndef RRT_PICK_POLICY
 #define RRT_PICK_POLICY 3
 #endif
@@ -1546,8 +1549,13 @@ __global__ __launch_bounds__(64, kWalk == kWalkBundle ? RRT_WAVES_BUNDLE : kWalk
     const uint32_t pix = lane >> 2, sub = lane & 3u;
     const bool tile_ok = tile < F.tile_end;
     const uint32_t tx = tile_ok ? tile % F.tiles_x : 0, ty = tile_ok ? tile / F.tiles_x : 0;
+#if RRT_WAVE_FOOTPRINT == 1        // 8 x 2 pixels per wave (experiment: 32-byte row segments instead of 16)
+    const uint32_t px = tx * 8 + (pix & 7u);
+    const uint32_t py = ty * 8 + quad * 2 + (pix >> 3);
+#else                               // 4 x 4 pixels per wave
     const uint32_t px = tx * 8 + (quad & 1u) * 4 + (pix & 3u);
     const uint32_t py = ty * 8 + (quad >> 1) * 4 + (pix >> 2);
+#endif
     const int32_t W = (int32_t)F.width, H = (int32_t)F.height;
     // put_pixel (engine.rs:146-158): new_x = x + W/2, new_y = H - (y + H/2); draw_scene loops x in [-W/2, W/2), y in [-H/2, H/2)
     // (engine.rs:198,205).  Pixels with no (x,y) in range stay 0 (Canvas::new, engine.rs:135): row 0 (rows 0,1 for odd H) and,
