@@ -113,19 +113,11 @@ template <class F> void for_each_line(sv text, F&& fn) {
 // spot); everything that can fail fails where and when it did before.
 struct TexturePrefetch {
     struct Image { std::vector<uint8_t> bytes; uint32_t w = 0, h = 0, ch = 0; };
-    std::mutex mu; std::condition_variable cv; bool done = false;
+    std::mutex mu;
     std::unordered_map<std::string, Image> images;                        // by path
+    std::unique_ptr<AsyncTask> task;
     static std::shared_ptr<TexturePrefetch> start(const std::string& dir, sv head);
-    // Called on the loader's own thread, never from a range running on the pool: a pool thread that waits here may, while helping, have been handed
-    // this very prefetch's task further down its stack, and would wait for itself (parallel.hpp: a task waits for its own children only).
-    void wait() {
-        for (;;) {
-            { std::lock_guard<std::mutex> g(mu); if (done) return; }
-            if (HostPool::get().run_one()) continue;
-            std::unique_lock<std::mutex> lk(mu);
-            if (!done) cv.wait_for(lk, std::chrono::microseconds(200));
-        }
-    }
+    void wait() { if (task) task->wait(); }                               // (decodes here and now if no worker has started on it)
     bool take(const std::string& path, Image& out) {                     // after wait()
         std::lock_guard<std::mutex> g(mu);
         auto it = images.find(path);
@@ -395,7 +387,8 @@ std::shared_ptr<TexturePrefetch> TexturePrefetch::start(const std::string& dir, 
     });
     if (mtl.empty() || host_threads() < 2) return nullptr;
     auto self = std::make_shared<TexturePrefetch>();
-    HostPool::get().submit([self, dir, mtl] {
+    TexturePrefetch* raw = self.get();                                    // (the task is owned by *self: it ends before self does)
+    self->task.reset(new AsyncTask([raw, dir, mtl] {
         try {
             const std::string text = read_file(dir + mtl);
             std::vector<std::string> names;
@@ -412,12 +405,10 @@ std::shared_ptr<TexturePrefetch> TexturePrefetch::start(const std::string& dir, 
                     catch (...) { got[i] = Image{}; }                     // not kept: the directive decodes it again and reports what is wrong with it
                 }
             });
-            std::lock_guard<std::mutex> g(self->mu);
-            for (size_t i = 0; i < names.size(); i++) if (!got[i].bytes.empty()) self->images.emplace(dir + names[i], std::move(got[i]));
+            std::lock_guard<std::mutex> g(raw->mu);
+            for (size_t i = 0; i < names.size(); i++) if (!got[i].bytes.empty()) raw->images.emplace(dir + names[i], std::move(got[i]));
         } catch (...) {}
-        { std::lock_guard<std::mutex> g(self->mu); self->done = true; }
-        self->cv.notify_all();
-    });
+    }));
     return self;
 }
 

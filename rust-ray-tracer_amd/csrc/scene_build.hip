@@ -588,12 +588,13 @@ struct DevFree { void* p = nullptr; ~DevFree() { if (p) (void)hipFree(p); } };
 // A slot's event says when the DMA that last used it has finished; a slot is waited for right before it is reused, never at the end of a call.
 struct StagingRing {
     static constexpr int kSlots = 8; static constexpr size_t kSlotBytes = (size_t)4 << 20;
-    char* mem = nullptr; hipEvent_t ev[kSlots] = {}; bool busy[kSlots] = {}; size_t next = 0; hipStream_t stream = nullptr;
+    char* mem = nullptr; hipEvent_t ev[kSlots] = {}; bool busy[kSlots] = {}; size_t next = 0; hipStream_t stream = nullptr, stream2 = nullptr;
     void ensure() {
         if (mem) return;
         HB_TRY(hipHostMalloc((void**)&mem, kSlots * kSlotBytes, hipHostMallocDefault));
         for (auto& e : ev) HB_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         HB_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));   // the device's set-up stream (creating one costs ~3 ms: done once, by the warm-up thread when it runs)
+        HB_TRY(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));  // uploads beside the build (upload_stream)
     }
     int acquire() {                                                     // next slot, free to be written
         const int s = (int)(next++ % kSlots);
@@ -623,6 +624,7 @@ void copy_bytes(char* dst, const char* src, size_t len) {
 void staged_upload_warm() { try { std::lock_guard<std::mutex> lk(g_ring_mu); (void)ring_of_current_device(); } catch (...) { (void)hipGetLastError(); } }
 
 void* setup_stream() { std::lock_guard<std::mutex> lk(g_ring_mu); return ring_of_current_device().stream; }
+void* upload_stream() { std::lock_guard<std::mutex> lk(g_ring_mu); return ring_of_current_device().stream2; }
 
 void staged_upload(void* dst, const void* src, size_t bytes, void* stream_) {
     if (!bytes) return;
@@ -691,7 +693,7 @@ void staged_download(void* dst, const void* src_dev, size_t bytes, void* stream_
     }
 }
 
-void gpu_build_scene(const TriSource& src, uint32_t n, const Box& root, bool enable_cull, const double origin[3], void* stream_, GpuScene& out) {
+void gpu_build_scene(const TriSource& src, uint32_t n, const Box& root, bool enable_cull, const double origin[3], void* stream_, GpuScene& out, const std::function<void()>& after_upload) {
     hipStream_t st = (hipStream_t)stream_;
     const bool trace = std::getenv("RRT_SETUP_TRACE") != nullptr;          // developer: host wall time of every stage (synchronising: not the production timing)
     auto lap = [&, last = std::chrono::steady_clock::now()](const char* what) mutable {
@@ -731,6 +733,7 @@ void gpu_build_scene(const TriSource& src, uint32_t n, const Box& root, bool ena
         hipLaunchKernelGGL(k_pack_triangles, dim3(grid_for(n)), dim3(kBlock), 0, st, d_pos, d_uv, d_nrm, d_mat, n, d_tris);
     }
     HB_TRY(hipEventRecord(evs[1], st));
+    if (after_upload) after_upload();
     lap("triangle upload (pinned staging)");
 
     Oct S{};

@@ -4,6 +4,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <functional>
 
 #include "device_scene.hpp"
 #include "model.hpp"
@@ -34,7 +35,10 @@ struct HipBuildFail { int hip_error; const char* what; };
 // The triangles either as the model's array (Triangle records, SceneData.triangles) or as the caller's own arrays (rrt_raytracer_create_from_arrays:
 // pos / uv / nrm [n][3][3] doubles, mat [n]) -- those are uploaded as they are and packed into Triangle records on the device.
 struct TriSource { const Triangle* tris = nullptr; const double* pos = nullptr; const double* uv = nullptr; const double* nrm = nullptr; const uint32_t* mat = nullptr; };
-void gpu_build_scene(const TriSource& src, uint32_t n_tris, const Box& root, bool enable_cull, const double origin[3], void* stream, GpuScene& out);
+// `after_upload` (may be empty) is called once the triangles have been handed to the staging ring, before the octree build: the caller's other uploads
+// (textures) can start there, beside the build, without competing with the triangles for the ring.
+void gpu_build_scene(const TriSource& src, uint32_t n_tris, const Box& root, bool enable_cull, const double origin[3], void* stream, GpuScene& out,
+                     const std::function<void()>& after_upload = {});
 
 // Pinned-staging upload of a host buffer (pageable or not) to device memory on `stream`: worker threads fill a ring of page-locked chunks while
 // the DMA engine drains it.  Returns after the last chunk has been ENQUEUED and copied out of `src` (src may be freed; dst is ready after a stream sync).
@@ -45,5 +49,6 @@ void staged_download(void* dst, const void* src_dev, size_t bytes, void* stream)
 // The current device's shared non-blocking stream (hipStream_t) for set-up work and blocking host-framebuffer renders: creating a stream costs
 // milliseconds, the reference's whole frame takes less.  Owned by the library; never destroyed.
 void* setup_stream();
+void* upload_stream();    // a second one, for uploads that run beside work on setup_stream() (textures beside the scene build)
 
 }  // namespace rrt

@@ -15,6 +15,25 @@ pytestmark = pytest.mark.gpu
 COLOUR_TOL = 1   # per RGB channel, BASELINE.json
 
 
+def _free_port():
+    """A port nobody listens on right now, with room above it: bench.py's children rendezvous on MASTER_PORT + 11 + k, and a fixed number taken from the pid
+    met the lingering socket of an earlier test's killed group once in a while."""
+    import socket
+    for _ in range(50):
+        with socket.socket() as a:
+            a.bind(("127.0.0.1", 0)); p = a.getsockname()[1]
+        if p > 60000:
+            continue
+        try:
+            for q in (p + 1, p + 11, p + 12):
+                with socket.socket() as b:
+                    b.bind(("127.0.0.1", q))
+            return p
+        except OSError:
+            continue
+    return 29500
+
+
 @pytest.fixture(scope="module")
 def teapot_rt(rrt, teapot):
     return rrt.RayTracer(teapot, rrt.default_lights(), rrt.DEFAULT_ORIGIN, device=0)
@@ -448,7 +467,7 @@ def test_bench_multi_gpu_choreography_single_rank():
     import json, subprocess, sys
     root = os.path.dirname(ASSETS)
     def run(env_extra, *flags):
-        env = dict(os.environ, MASTER_PORT=str(29600 + os.getpid() % 300), **env_extra)
+        env = dict(os.environ, MASTER_PORT=str(_free_port()), **env_extra)
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--steps", "6", "--warmup", "2", "--width", "320", "--height", "240", *flags],
                            capture_output=True, text=True, env=env, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -536,11 +555,11 @@ def test_bench_two_ranks_in_both_launch_modes_rehearsal():
         lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
         assert len(lines) == 1, r.stdout
         return json.loads(lines[0])
-    port = 29700 + os.getpid() % 200
+    port, port2 = _free_port(), _free_port()
     env = dict(os.environ, RRT_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     single = one_line(subprocess.run([sys.executable, os.path.join(root, "bench.py"), *common, "--no-first-frame", "--no-host-fb"], capture_output=True, text=True, env=dict(os.environ), timeout=600))
     plain = one_line(subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", *common], capture_output=True, text=True, env=env, timeout=900))
-    launched = one_line(subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port + 40),
+    launched = one_line(subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port2),
                                         os.path.join(root, "bench.py"), "--gpus", "2", *common], capture_output=True, text=True, env=dict(os.environ, RRT_BENCH_REHEARSAL="1"), timeout=900))
     for out in (plain, launched):
         assert out["n_gpus"] == 2 and out["frame_checksum"] == single["frame_checksum"] and "rehearsal" in out and set(out["gather_paths"]) == {"torch", "lib"}
