@@ -26,9 +26,14 @@
 
 namespace rrt {
 
+// Threads a parallel stage may use: RRT_HOST_THREADS, else the hardware threads -- divided by the ranks of this node when the process is one of
+// several (LOCAL_WORLD_SIZE, else WORLD_SIZE: one process per GPU, all loading the same scene at the same moment) -- and at most 128.
 inline unsigned host_threads() {
     if (const char* e = std::getenv("RRT_HOST_THREADS")) { const int v = std::atoi(e); if (v >= 1) return (unsigned)std::min(v, 256); }
-    const unsigned hc = std::thread::hardware_concurrency();
+    unsigned hc = std::thread::hardware_concurrency();
+    const char* w = std::getenv("LOCAL_WORLD_SIZE");
+    if (!w) w = std::getenv("WORLD_SIZE");
+    if (w) { const int ranks = std::atoi(w); if (ranks > 1) hc = std::max(1u, hc / (unsigned)std::min(ranks, 64)); }
     return std::max(1u, std::min(hc ? hc : 1u, 128u));     // (the 1 M-triangle .obj, 253 MB of text: 32 ranges 22 ms, 128 ranges 6 ms on a 256-thread host)
 }
 

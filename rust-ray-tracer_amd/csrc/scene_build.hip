@@ -586,8 +586,14 @@ struct DevFree { void* p = nullptr; ~DevFree() { if (p) (void)hipFree(p); } };
 
 // ---- pinned staging: one ring of page-locked chunks per device, shared by every upload and every pageable-framebuffer download of the process.
 // A slot's event says when the DMA that last used it has finished; a slot is waited for right before it is reused, never at the end of a call.
+#ifndef RRT_RING_SLOTS
+#define RRT_RING_SLOTS 8
+#endif
+#ifndef RRT_RING_SLOT_MB
+#define RRT_RING_SLOT_MB 4
+#endif
 struct StagingRing {
-    static constexpr int kSlots = 8; static constexpr size_t kSlotBytes = (size_t)4 << 20;
+    static constexpr int kSlots = RRT_RING_SLOTS; static constexpr size_t kSlotBytes = (size_t)RRT_RING_SLOT_MB << 20;
     char* mem = nullptr; hipEvent_t ev[kSlots] = {}; bool busy[kSlots] = {}; size_t next = 0; hipStream_t stream = nullptr, stream2 = nullptr;
     void ensure() {
         if (mem) return;
