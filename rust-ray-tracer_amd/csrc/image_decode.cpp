@@ -1,5 +1,5 @@
-// image_decode.cpp -- build-owned texture decode: baseline/extended-sequential Huffman JPEG (8-bit, unsubsampled
-// or greyscale) and non-interlaced 8-bit PNG.  Stands where the reference calls the `image` crate
+// image_decode.cpp -- build-owned texture decode: Huffman JPEG (8-bit; sequential or progressive; 4:4:4, 4:2:2, 4:2:0 or greyscale; one scan
+// or many; restart markers) and non-interlaced 8-bit PNG.  Stands where the reference calls the `image` crate
 // (`ImageReader::open(..).decode()`, src/file_management/utils.rs:345-350; image 0.25.9 -> zune-jpeg 0.5.8 / png 0.18.0,
 // Cargo.lock).  Those crates are not in the reference tree, JPEG decoders are not bit-identical to one another and no
 // reference test pins decoded texels, so parity at this boundary is UNPINNED: the hot path's input is
@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 
 #include "model.hpp"
 #include "parallel.hpp"
@@ -173,13 +174,18 @@ void idct_islow(const int32_t in[64], uint8_t* out, size_t stride) {
     }
 }
 
-struct Component { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0; int pred = 0; };
+struct Component {
+    int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0; int pred = 0;
+    uint32_t bw = 0, bh = 0;          // block grid, padded to whole MCUs of the frame
+    uint32_t w = 0, hgt = 0;          // samples that belong to the image: ceil(W h / hmax), ceil(H v / vmax)
+    std::vector<int16_t> coef;        // planar coefficients (multi-scan files only): bw x bh x 64
+};
 
 // ---- phase 1 on several threads.  A Huffman stream has no index: where block 20 000 starts is known only after decoding the 19 999 before it.  But a
-// decoder dropped into the middle of the stream -- wrong bit, wrong component, wrong coefficient -- falls into step with the true decode after a few
-// blocks (the codes are short and the end-of-block code keeps re-aligning it), and from the first block START the two share (same bit position, same
-// component) they decode the same thing for ever: the parse has no other state.  So: the scan (stuffed zeros removed) is cut into T byte ranges; decoder
-// i starts at the first bit of range i as if a block of component 0 began there, notes (bit position, component) of every block it starts, and keeps its
+// decoder dropped into the middle of the stream -- wrong bit, wrong block of the MCU, wrong coefficient -- falls into step with the true decode after a
+// few blocks (the codes are short and the end-of-block code keeps re-aligning it), and from the first block START the two share (same bit position, same
+// place in the MCU) they decode the same thing for ever: the parse has no other state.  So: the scan (stuffed zeros removed) is cut into T byte ranges;
+// decoder i starts at the first bit of range i as if an MCU began there, notes (bit position, place in the MCU) of every block it starts, and keeps its
 // blocks in a buffer of its own; when all have crossed their range, decoder i runs on into range i + 1 until it starts a block exactly where decoder
 // i + 1 started one.  Decoder 0 is right from its first bit, so by induction everything from each meeting point on is right; what a decoder produced
 // before it was met is dropped.  DC values are differences against a predictor the late starters do not know: they count from 0 and the true value at
@@ -200,29 +206,32 @@ struct CleanReader {
     uint64_t bitpos() const { return (uint64_t)pos * 8 - (uint64_t)nbits; }
 };
 
+// The blocks of one MCU of an interleaved scan, in stream order: slot -> component (a 4:2:0 MCU is Y Y Y Y Cb Cr; at most 10 blocks, T.81 B.2.3).
+struct McuLayout { int n_slots = 0; int comp_of[10] = {}; const Huff* dct[10] = {}; const Huff* act[10] = {}; };
+
 struct ScanPart {
     std::vector<int16_t> coef;        // 64 per block, AC filled in; [0] written by the stitch
     std::vector<int32_t> dc;          // per block: DC with the part's predictors starting from 0
-    std::vector<uint64_t> start;      // per block: bit position << 2 | component
+    std::vector<uint64_t> start;      // per block: bit position << 4 | slot in the MCU
     std::vector<uint32_t> bad;        // blocks that broke a rule (expected before the part has fallen into step, fatal after)
-    CleanReader br{nullptr, 0}; int comp = 0; int32_t pred[4] = {0, 0, 0, 0};
+    CleanReader br{nullptr, 0}; int slot = 0; int32_t pred[4] = {0, 0, 0, 0};
     size_t n_main = 0;                // blocks that start inside the part's own range
     bool met = false; size_t met_at = 0, met_next = 0; int32_t pred_at_meeting[4] = {0, 0, 0, 0};
-    void one_block(const Huff* const* dct, const Huff* const* act, int nc) {
+    void one_block(const McuLayout& L) {
         const size_t b = start.size();
-        start.push_back((br.bitpos() << 2) | (uint64_t)comp);
+        start.push_back((br.bitpos() << 4) | (uint64_t)slot);
         coef.resize((b + 1) * 64, 0);
         int diff = 0;
-        const int e = decode_block(br, *dct[comp], *act[comp], diff, &coef[b * 64]);
-        if (e) { bad.push_back((uint32_t)b); dc.push_back(0); comp = 0; return; }      // (out of step: try again from here as component 0)
-        pred[comp] += diff; dc.push_back(pred[comp]);
-        comp = comp + 1 == nc ? 0 : comp + 1;
+        const int e = decode_block(br, *L.dct[slot], *L.act[slot], diff, &coef[b * 64]);
+        if (e) { bad.push_back((uint32_t)b); dc.push_back(0); slot = 0; return; }      // (out of step: try again from here as the first block of an MCU)
+        const int c = L.comp_of[slot];
+        pred[c] += diff; dc.push_back(pred[c]);
+        slot = slot + 1 == L.n_slots ? 0 : slot + 1;
     }
 };
 
-bool entropy_parallel(const uint8_t* scan, const uint8_t* end, const std::vector<Component>& comps, const Huff* dc_tab, const Huff* ac_tab, size_t n_total /* blocks x components */,
+bool entropy_parallel(const uint8_t* scan, const uint8_t* end, const McuLayout& L, int nc, size_t n_total /* blocks of the scan */,
                       std::vector<ScanPart>& parts, std::vector<const int16_t*>& block_ptr) {
-    const int nc = (int)comps.size();
     const bool trace = std::getenv("RRT_SETUP_TRACE") != nullptr;
     auto lap = [&, last = std::chrono::steady_clock::now()](const char* what) mutable {
         if (!trace) return;
@@ -243,8 +252,7 @@ bool entropy_parallel(const uint8_t* scan, const uint8_t* end, const std::vector
     if (const char* e = std::getenv("RRT_JPEG_PART_BYTES")) part_bytes = std::max<size_t>(8, (size_t)std::atoll(e));   // (tests: the stitching on small files)
     const size_t T = std::min<size_t>({(size_t)host_threads(), (size_t)24, nb / part_bytes});
     if (T < 2 || n_total >= (1ull << 32) || nb >= (1ull << 40)) return false;
-    const Huff* dct[4]; const Huff* act[4];
-    for (int c = 0; c < nc; c++) { dct[c] = &dc_tab[comps[c].td]; act[c] = &ac_tab[comps[c].ta]; }
+    const int ns = L.n_slots;
     parts.assign(T, ScanPart{});
     auto part_end_bit = [&](size_t i) { return (uint64_t)(i + 1 == T ? nb : nb * (i + 1) / T) * 8; };
     parallel_ranges(T, 1, [&](size_t b, size_t e, size_t) {
@@ -254,7 +262,7 @@ bool entropy_parallel(const uint8_t* scan, const uint8_t* end, const std::vector
             const size_t guess = n_total / T + n_total / (4 * T) + 64;
             P.coef.reserve(guess * 64); P.dc.reserve(guess); P.start.reserve(guess);
             const uint64_t stop = part_end_bit(i);
-            while (P.br.bitpos() < stop && P.start.size() < n_total + 8) P.one_block(dct, act, nc);
+            while (P.br.bitpos() < stop && P.start.size() < n_total + 8) P.one_block(L);
             P.n_main = P.start.size();
         }
     });
@@ -264,11 +272,12 @@ bool entropy_parallel(const uint8_t* scan, const uint8_t* end, const std::vector
             ScanPart& P = parts[i]; const ScanPart& N = parts[i + 1];
             size_t r = 0;
             for (;;) {
-                const uint64_t key = (P.br.bitpos() << 2) | (uint64_t)P.comp;
-                while (r < N.n_main && (N.start[r] >> 2) < (key >> 2)) r++;
+                const uint64_t key = (P.br.bitpos() << 4) | (uint64_t)P.slot;
+                while (r < N.n_main && (N.start[r] >> 4) < (key >> 4)) r++;
                 if (r >= N.n_main) break;                                            // crossed the whole next range without meeting its decoder
                 if (N.start[r] == key) { P.met = true; P.met_at = P.start.size(); P.met_next = r; std::memcpy(P.pred_at_meeting, P.pred, sizeof P.pred); break; }
-                P.one_block(dct, act, nc);
+                if (P.start.size() >= n_total + 8) break;
+                P.one_block(L);
             }
         }
     });
@@ -282,10 +291,10 @@ bool entropy_parallel(const uint8_t* scan, const uint8_t* end, const std::vector
         keep_to[i] = P.met_at; keep_from[i + 1] = P.met_next;
         first_global[i + 1] = first_global[i] + (int64_t)P.met_at - (int64_t)P.met_next;
         const int64_t g = first_global[i] + (int64_t)P.met_at;
-        if (g < 0 || (int)(g % nc) != (int)(N.start[P.met_next] & 3u)) return false;
+        if (g < 0 || (int)(g % ns) != (int)(N.start[P.met_next] & 15u)) return false;
         for (int c = 0; c < nc; c++) {
             int64_t local = 0;                                                       // the next part's own predictor of component c when it started the meeting block
-            for (size_t k = P.met_next; k-- > 0;) if ((int)(N.start[k] & 3u) == c && !std::binary_search(N.bad.begin(), N.bad.end(), (uint32_t)k)) { local = N.dc[k]; break; }
+            for (size_t k = P.met_next; k-- > 0;) if (L.comp_of[N.start[k] & 15u] == c && !std::binary_search(N.bad.begin(), N.bad.end(), (uint32_t)k)) { local = N.dc[k]; break; }
             offset[i + 1][c] = (int64_t)P.pred_at_meeting[c] + offset[i][c] - local;
         }
     }
@@ -299,9 +308,9 @@ bool entropy_parallel(const uint8_t* scan, const uint8_t* end, const std::vector
             for (size_t k = keep_from[i]; k < keep_to[i]; k++) {
                 const int64_t g = first_global[i] + (int64_t)k;
                 if (g >= (int64_t)n_total) break;
-                const int c = (int)(P.start[k] & 3u);
-                const int64_t v = (int64_t)P.dc[k] + offset[i][c];
-                if (g < 0 || (int)(g % nc) != c || v < -32768 || v > 32767) { ok[i] = 0; break; }
+                const int s = (int)(P.start[k] & 15u);
+                const int64_t v = (int64_t)P.dc[k] + offset[i][L.comp_of[s]];
+                if (g < 0 || (int)(g % ns) != s || v < -32768 || v > 32767) { ok[i] = 0; break; }
                 P.coef[k * 64] = (int16_t)v; block_ptr[(size_t)g] = &P.coef[k * 64];
             }
             for (uint32_t k : P.bad) if (k >= keep_from[i] && k < keep_to[i] && first_global[i] + (int64_t)k < (int64_t)n_total) ok[i] = 0;
@@ -318,6 +327,89 @@ bool entropy_parallel(const uint8_t* scan, const uint8_t* end, const std::vector
     return true;
 }
 
+// ---- scans of a progressive frame (T.81 annex G; the procedures of IJG's jdphuff.c), one block at a time into the component's coefficient plane
+struct ProgressiveState { uint32_t eobrun = 0; };
+inline void store_coef(int16_t* dst, int32_t v) {
+    if (v < -32768 || v > 32767) fail(RRT_ERR_PARSE, "Cannot decode texture file: coefficient out of range");
+    *dst = (int16_t)v;
+}
+void prog_dc_first(BitReader& br, const Huff& dct, Component& c, int Al, int16_t* blk) {
+    const int t = decode_symbol(br, dct);
+    if (t < 0) fail(RRT_ERR_PARSE, block_error_text(kBadCode));
+    if (t > 11) fail(RRT_ERR_PARSE, block_error_text(kBadDcCategory));
+    c.pred += t ? extend(br.bits(t), t) : 0;
+    if (c.pred < -32768 || c.pred > 32767) fail(RRT_ERR_PARSE, "Cannot decode texture file: DC predictor out of range");
+    store_coef(blk, c.pred * (1 << Al));
+}
+void prog_dc_refine(BitReader& br, int Al, int16_t* blk) { if (br.bit()) blk[0] = (int16_t)(blk[0] | (1 << Al)); }
+void prog_ac_first(BitReader& br, const Huff& act, ProgressiveState& st, int Ss, int Se, int Al, int16_t* blk) {
+    if (st.eobrun) { st.eobrun--; return; }
+    for (int k = Ss; k <= Se; k++) {
+        const int rs = decode_symbol(br, act);
+        if (rs < 0) fail(RRT_ERR_PARSE, block_error_text(kBadCode));
+        const int r = rs >> 4, s = rs & 15;
+        if (s) {
+            k += r;
+            if (k > Se) fail(RRT_ERR_PARSE, block_error_text(kBadAcRun));
+            if (s > 14) fail(RRT_ERR_PARSE, block_error_text(kBadAcSize));
+            store_coef(&blk[kZigzag[k]], extend(br.bits(s), s) * (1 << Al));
+        } else if (r == 15) k += 15;
+        else { st.eobrun = 1u << r; if (r) st.eobrun += (uint32_t)br.bits(r); st.eobrun--; break; }
+    }
+}
+void prog_ac_refine(BitReader& br, const Huff& act, ProgressiveState& st, int Ss, int Se, int Al, int16_t* blk) {
+    const int p1 = 1 << Al, m1 = -(1 << Al);
+    auto correct = [&](int16_t* q) {                                    // one more bit of a coefficient that is already non-zero
+        if (br.bit() && (*q & p1) == 0) *q = (int16_t)(*q + (*q >= 0 ? p1 : m1));
+    };
+    int k = Ss;
+    if (st.eobrun == 0) {
+        for (; k <= Se; k++) {
+            const int rs = decode_symbol(br, act);
+            if (rs < 0) fail(RRT_ERR_PARSE, block_error_text(kBadCode));
+            int r = rs >> 4, s = rs & 15;
+            if (s) {
+                if (s != 1) fail(RRT_ERR_PARSE, block_error_text(kBadAcSize));
+                s = br.bit() ? p1 : m1;
+            } else if (r != 15) { st.eobrun = 1u << r; if (r) st.eobrun += (uint32_t)br.bits(r); break; }
+            // pass the coefficients that are already non-zero (each takes a correction bit) and r zero ones
+            do {
+                int16_t* q = &blk[kZigzag[k]];
+                if (*q != 0) correct(q);
+                else if (--r < 0) break;
+                k++;
+            } while (k <= Se);
+            if (s) { if (k > Se) fail(RRT_ERR_PARSE, block_error_text(kBadAcRun)); blk[kZigzag[k]] = (int16_t)s; }
+        }
+    }
+    if (st.eobrun) {
+        for (; k <= Se; k++) { int16_t* q = &blk[kZigzag[k]]; if (*q != 0) correct(q); }
+        st.eobrun--;
+    }
+}
+
+// libjpeg's "fancy" (triangle-filter) chroma upsampling, jdsample.c: h2v1_fancy_upsample / h2v2_fancy_upsample, sample for sample; w > 2 (narrower
+// components are replicated, as there).  `out` takes 2 w samples.
+void upsample_h2v1(const uint8_t* in, uint32_t w, uint8_t* out) {
+    int v = *in++;
+    *out++ = (uint8_t)v; *out++ = (uint8_t)((v * 3 + in[0] + 2) >> 2);
+    for (uint32_t n = w - 2; n > 0; n--) { v = (*in++) * 3; *out++ = (uint8_t)((v + in[-2] + 1) >> 2); *out++ = (uint8_t)((v + in[0] + 2) >> 2); }
+    v = *in;
+    *out++ = (uint8_t)((v * 3 + in[-1] + 1) >> 2); *out++ = (uint8_t)v;
+}
+void upsample_h2v2(const uint8_t* near, const uint8_t* far, uint32_t w, uint8_t* out) {
+    int cur = near[0] * 3 + far[0], next = near[1] * 3 + far[1], last;
+    near += 2; far += 2;
+    *out++ = (uint8_t)((cur * 4 + 8) >> 4); *out++ = (uint8_t)((cur * 3 + next + 7) >> 4);
+    last = cur; cur = next;
+    for (uint32_t n = w - 2; n > 0; n--) {
+        next = (*near++) * 3 + (*far++);
+        *out++ = (uint8_t)((cur * 3 + last + 8) >> 4); *out++ = (uint8_t)((cur * 3 + next + 7) >> 4);
+        last = cur; cur = next;
+    }
+    *out++ = (uint8_t)((cur * 3 + last + 8) >> 4); *out++ = (uint8_t)((cur * 4 + 7) >> 4);
+}
+
 void decode_jpeg(const std::vector<uint8_t>& buf, std::vector<uint8_t>& out, uint32_t& W, uint32_t& H, uint32_t& channels) {
     const uint8_t* p = buf.data(); const uint8_t* end = p + buf.size();
     auto need = [&](size_t n) { if ((size_t)(end - p) < n) fail(RRT_ERR_PARSE, "Cannot decode texture file: truncated JPEG"); };
@@ -327,147 +419,254 @@ void decode_jpeg(const std::vector<uint8_t>& buf, std::vector<uint8_t>& out, uin
     uint16_t qt[4][64] = {}; bool qt_present[4] = {};
     Huff dc[4], ac[4];
     std::vector<Component> comps;
-    int restart_interval = 0; bool have_sof = false; int adobe_transform = -1;
-    for (;;) {
-        need(2);
-        if (p[0] != 0xFF) fail(RRT_ERR_PARSE, "Cannot decode texture file: marker expected");
-        while (p < end && p[0] == 0xFF && p + 1 < end && p[1] == 0xFF) p++;   // fill bytes
-        uint8_t m = p[1]; p += 2;
-        if (m == 0xD9) fail(RRT_ERR_PARSE, "Cannot decode texture file: no scan");
-        if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
-        need(2);
-        size_t L = ((size_t)p[0] << 8) | p[1];
-        if (L < 2) fail(RRT_ERR_PARSE, "Cannot decode texture file: bad segment");
-        need(L);
-        const uint8_t* s = p + 2; const uint8_t* se = p + L;
-        if (m == 0xDB) {                                    // DQT
-            while (s < se) {
-                int pq = s[0] >> 4, tq = s[0] & 15; s++;
-                if (tq > 3 || (size_t)(se - s) < (size_t)(pq ? 128 : 64)) fail(RRT_ERR_PARSE, "Cannot decode texture file: bad DQT");
-                for (int k = 0; k < 64; k++) { qt[tq][kZigzag[k]] = pq ? (uint16_t)((s[0] << 8) | s[1]) : s[0]; s += pq ? 2 : 1; }
-                qt_present[tq] = true;
-            }
-        } else if (m == 0xC4) {                             // DHT
-            while (s < se) {
-                if (se - s < 17) fail(RRT_ERR_PARSE, "Cannot decode texture file: bad DHT");
-                int tc = s[0] >> 4, th = s[0] & 15; s++;
-                const uint8_t* counts = s; s += 16;
-                int n = 0; for (int k = 0; k < 16; k++) n += counts[k];
-                if (th > 3 || tc > 1 || n > 256 || se - s < n) fail(RRT_ERR_PARSE, "Cannot decode texture file: bad DHT");
-                (tc ? ac : dc)[th].build(counts, s, n); s += n;
-            }
-        } else if (m == 0xC0 || m == 0xC1) {                // SOF0 / SOF1 (Huffman, sequential)
-            if (L < 8 || s[0] != 8) fail(RRT_ERR_UNSUPPORTED, "JPEG: only 8-bit precision");
-            H = (s[1] << 8) | s[2]; W = (s[3] << 8) | s[4];
-            int nc = s[5];
-            if ((nc != 1 && nc != 3) || L < (size_t)(8 + 3 * nc) || W == 0 || H == 0) fail(RRT_ERR_UNSUPPORTED, "JPEG: unsupported component count");
-            comps.resize(nc);
-            for (int k = 0; k < nc; k++) { comps[k].id = s[6 + 3 * k]; comps[k].h = s[7 + 3 * k] >> 4; comps[k].v = s[7 + 3 * k] & 15; comps[k].tq = s[8 + 3 * k] & 3; }
-            for (auto& c : comps) if (c.h != 1 || c.v != 1) fail(RRT_ERR_UNSUPPORTED, "JPEG: chroma subsampling is not supported");
-            have_sof = true;
-        } else if (m == 0xC2 || (m >= 0xC5 && m <= 0xCF && m != 0xC8 && m != 0xCC)) {
-            fail(RRT_ERR_UNSUPPORTED, "JPEG: only baseline/sequential Huffman");
-        } else if (m == 0xDD) {                             // DRI
-            if (L >= 4) restart_interval = (s[0] << 8) | s[1];
-        } else if (m == 0xEE) {                             // APP14 Adobe
-            if (L >= 14 && !std::memcmp(s, "Adobe", 5)) adobe_transform = s[11];
-        } else if (m == 0xDA) {                             // SOS
-            if (!have_sof) fail(RRT_ERR_PARSE, "Cannot decode texture file: SOS before SOF");
-            int ns = s[0];
-            if (ns != (int)comps.size() || L < (size_t)(6 + 2 * ns)) fail(RRT_ERR_UNSUPPORTED, "JPEG: non-interleaved scans are not supported");
-            for (int k = 0; k < ns; k++) {
-                int cid = s[1 + 2 * k]; bool found = false;
-                for (auto& c : comps) if (c.id == cid) { c.td = s[2 + 2 * k] >> 4; c.ta = s[2 + 2 * k] & 15; found = true; }
-                if (!found) fail(RRT_ERR_PARSE, "Cannot decode texture file: bad SOS");
+    int restart_interval = 0; bool have_sof = false, progressive = false; int adobe_transform = -1;
+    uint32_t mcus_x = 0, mcus_y = 0; int hmax = 1, vmax = 1;
+    struct Scan { int ns = 0; int ci[4] = {}; int Ss = 0, Se = 63, Ah = 0, Al = 0; };
+    // Markers up to and including the next SOS.  Returns false at EOI (or at the end of the data: a file cut after a scan still shows what it holds).
+    auto next_scan = [&](Scan& sc, bool first) -> bool {
+        for (;;) {
+            if ((size_t)(end - p) < 2) { if (first) fail(RRT_ERR_PARSE, "Cannot decode texture file: truncated JPEG"); return false; }
+            if (p[0] != 0xFF) { if (first) fail(RRT_ERR_PARSE, "Cannot decode texture file: marker expected"); p++; continue; }   // (between scans: bytes the entropy decoder left over)
+            while (p + 1 < end && p[1] == 0xFF) p++;            // fill bytes
+            if (p + 1 >= end) { if (first) fail(RRT_ERR_PARSE, "Cannot decode texture file: truncated JPEG"); return false; }
+            const uint8_t m = p[1]; p += 2;
+            if (m == 0xD9) { if (first) fail(RRT_ERR_PARSE, "Cannot decode texture file: no scan"); return false; }
+            if (m == 0x00 || m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
+            if ((size_t)(end - p) < 2) { if (first) fail(RRT_ERR_PARSE, "Cannot decode texture file: truncated JPEG"); return false; }
+            const size_t L = ((size_t)p[0] << 8) | p[1];
+            if (L < 2) fail(RRT_ERR_PARSE, "Cannot decode texture file: bad segment");
+            if ((size_t)(end - p) < L) { if (first) fail(RRT_ERR_PARSE, "Cannot decode texture file: truncated JPEG"); return false; }
+            const uint8_t* s = p + 2; const uint8_t* se = p + L;
+            if (m == 0xDB) {                                    // DQT
+                while (s < se) {
+                    int pq = s[0] >> 4, tq = s[0] & 15; s++;
+                    if (tq > 3 || (size_t)(se - s) < (size_t)(pq ? 128 : 64)) fail(RRT_ERR_PARSE, "Cannot decode texture file: bad DQT");
+                    for (int k = 0; k < 64; k++) { qt[tq][kZigzag[k]] = pq ? (uint16_t)((s[0] << 8) | s[1]) : s[0]; s += pq ? 2 : 1; }
+                    qt_present[tq] = true;
+                }
+            } else if (m == 0xC4) {                             // DHT
+                while (s < se) {
+                    if (se - s < 17) fail(RRT_ERR_PARSE, "Cannot decode texture file: bad DHT");
+                    int tc = s[0] >> 4, th = s[0] & 15; s++;
+                    const uint8_t* counts = s; s += 16;
+                    int n = 0; for (int k = 0; k < 16; k++) n += counts[k];
+                    if (th > 3 || tc > 1 || n > 256 || se - s < n) fail(RRT_ERR_PARSE, "Cannot decode texture file: bad DHT");
+                    (tc ? ac : dc)[th].build(counts, s, n); s += n;
+                }
+            } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {   // SOF0 / SOF1 (sequential) / SOF2 (progressive), Huffman
+                if (have_sof) fail(RRT_ERR_PARSE, "Cannot decode texture file: second frame header");
+                if (L < 8 || s[0] != 8) fail(RRT_ERR_UNSUPPORTED, "JPEG: only 8-bit precision");
+                H = (s[1] << 8) | s[2]; W = (s[3] << 8) | s[4];
+                const int nc = s[5];
+                if ((nc != 1 && nc != 3) || L < (size_t)(8 + 3 * nc) || W == 0 || H == 0) fail(RRT_ERR_UNSUPPORTED, "JPEG: unsupported component count");
+                comps.resize(nc);
+                for (int k = 0; k < nc; k++) { comps[k].id = s[6 + 3 * k]; comps[k].h = s[7 + 3 * k] >> 4; comps[k].v = s[7 + 3 * k] & 15; comps[k].tq = s[8 + 3 * k] & 3; }
+                if (nc == 1) comps[0].h = comps[0].v = 1;        // one component: never interleaved, its sampling factors mean nothing (T.81 A.2.2)
+                for (auto& c : comps) { if (c.h < 1 || c.v < 1) fail(RRT_ERR_PARSE, "Cannot decode texture file: bad sampling factor"); hmax = std::max(hmax, c.h); vmax = std::max(vmax, c.v); }
+                // what libjpeg upsamples with its triangle filters (and PIL pins here): full resolution, 2:1 horizontally, 2:1 both ways -- 4:4:4, 4:2:2, 4:2:0
+                for (auto& c : comps) {
+                    const bool full = c.h == hmax && c.v == vmax, h2v1 = c.h * 2 == hmax && c.v == vmax, h2v2 = c.h * 2 == hmax && c.v * 2 == vmax;
+                    if (!(full || h2v1 || h2v2) || hmax > 2 || vmax > 2) fail(RRT_ERR_UNSUPPORTED, "JPEG: chroma subsampling other than 4:4:4, 4:2:2 and 4:2:0 is not supported");
+                }
+                if (comps[0].h != hmax || comps[0].v != vmax) fail(RRT_ERR_UNSUPPORTED, "JPEG: a subsampled first component is not supported");
+                mcus_x = (W + 8 * hmax - 1) / (8 * hmax); mcus_y = (H + 8 * vmax - 1) / (8 * vmax);
+                for (auto& c : comps) { c.bw = mcus_x * c.h; c.bh = mcus_y * c.v; c.w = (W * c.h + hmax - 1) / hmax; c.hgt = (H * c.v + vmax - 1) / vmax; }
+                progressive = m == 0xC2; have_sof = true;
+            } else if (m >= 0xC3 && m <= 0xCF && m != 0xC8 && m != 0xCC) {
+                fail(RRT_ERR_UNSUPPORTED, "JPEG: only Huffman-coded sequential and progressive DCT");
+            } else if (m == 0xDD) {                             // DRI
+                if (L >= 4) restart_interval = (s[0] << 8) | s[1];
+            } else if (m == 0xEE) {                             // APP14 Adobe
+                if (L >= 14 && !std::memcmp(s, "Adobe", 5)) adobe_transform = s[11];
+            } else if (m == 0xDA) {                             // SOS
+                if (!have_sof) fail(RRT_ERR_PARSE, "Cannot decode texture file: SOS before SOF");
+                sc = Scan{};
+                sc.ns = s[0];
+                if (sc.ns < 1 || sc.ns > (int)comps.size() || L < (size_t)(6 + 2 * sc.ns)) fail(RRT_ERR_PARSE, "Cannot decode texture file: bad SOS");
+                for (int k = 0; k < sc.ns; k++) {
+                    const int cid = s[1 + 2 * k]; int found = -1;
+                    for (size_t c = 0; c < comps.size(); c++) if (comps[c].id == cid) { comps[c].td = s[2 + 2 * k] >> 4; comps[c].ta = s[2 + 2 * k] & 15; found = (int)c; }
+                    if (found < 0 || comps[found].td > 3 || comps[found].ta > 3) fail(RRT_ERR_PARSE, "Cannot decode texture file: bad SOS");
+                    for (int j = 0; j < k; j++) if (sc.ci[j] == found) fail(RRT_ERR_PARSE, "Cannot decode texture file: bad SOS");
+                    sc.ci[k] = found;
+                }
+                sc.Ss = s[1 + 2 * sc.ns]; sc.Se = s[2 + 2 * sc.ns]; sc.Ah = s[3 + 2 * sc.ns] >> 4; sc.Al = s[3 + 2 * sc.ns] & 15;
+                p += L;
+                return true;
             }
             p += L;
-            break;
         }
-        p += L;
-    }
-    for (auto& c : comps) if (!qt_present[c.tq] || c.td > 3 || c.ta > 3 || !dc[c.td].present || !ac[c.ta].present) fail(RRT_ERR_PARSE, "Cannot decode texture file: missing table");
-
-    const uint32_t bw = (W + 7) / 8, bh = (H + 7) / 8;
-    const size_t stride = (size_t)bw * 8;
-    // ---- phase 1: the entropy-coded segment -> quantised coefficients (natural order) of every block of every component.  On several threads when the
-    // scan is long and has no restart markers (entropy_parallel above); one block after the other otherwise, and whenever that attempt declines.
-    const size_t n_blocks = (size_t)bw * bh, nc = comps.size();
+    };
+    Scan sc;
+    next_scan(sc, true);
+    const size_t nc = comps.size();
+    for (auto& c : comps) if (!qt_present[c.tq]) fail(RRT_ERR_PARSE, "Cannot decode texture file: missing table");
     const bool trace = std::getenv("RRT_SETUP_TRACE") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
+
+    // ---- phase 1: the entropy-coded data -> quantised coefficients (natural order) of every block of every component
     std::vector<int16_t> coef; std::vector<ScanPart> parts; std::vector<const int16_t*> block_ptr;
-    const bool in_parallel = !restart_interval && !std::getenv("RRT_JPEG_SERIAL") && entropy_parallel(p, end, comps, dc, ac, n_blocks * nc, parts, block_ptr);
-    if (!in_parallel) {
-        parts.clear();
-        coef.assign(n_blocks * nc * 64, 0);
-        block_ptr.resize(n_blocks * nc);
-        for (size_t g = 0; g < n_blocks * nc; g++) block_ptr[g] = &coef[g * 64];
-        BitReader br{p, end};
-        int to_restart = restart_interval;
-        for (uint32_t by = 0; by < bh; by++) {
-            for (uint32_t bx = 0; bx < bw; bx++) {
-                if (restart_interval && to_restart == 0) {
-                    // byte-align, expect RSTn (the reader never passes a marker: it is at or ahead of br.p)
-                    const uint8_t* q = br.p;
-                    while (q + 1 < end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) q++;
-                    if (q + 1 >= end) fail(RRT_ERR_PARSE, "Cannot decode texture file: missing RST");
-                    br.reset_at(q + 2);
-                    for (auto& c : comps) c.pred = 0;
-                    to_restart = restart_interval;
+    McuLayout layout; int slot_base[4] = {};
+    for (size_t c = 0; c < nc; c++) { slot_base[c] = layout.n_slots; for (int k = 0; k < comps[c].h * comps[c].v; k++) layout.comp_of[layout.n_slots++] = (int)c; }
+    const size_t n_stream = (size_t)mcus_x * mcus_y * layout.n_slots;
+    const bool one_scan = !progressive && sc.ns == (int)nc;            // the usual file: one interleaved scan holds everything
+    bool in_parallel = false;
+    auto restart_if_due = [&](BitReader& br, int& to_restart, ProgressiveState* ps) {
+        if (!restart_interval || to_restart != 0) return;
+        const uint8_t* q = br.p;                                        // byte-align, expect RSTn (the reader never passes a marker: it is at or ahead of br.p)
+        while (q + 1 < end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) q++;
+        if (q + 1 >= end) fail(RRT_ERR_PARSE, "Cannot decode texture file: missing RST");
+        br.reset_at(q + 2);
+        for (auto& c : comps) c.pred = 0;
+        if (ps) ps->eobrun = 0;
+        to_restart = restart_interval;
+    };
+    if (one_scan) {
+        for (auto& c : comps) if (!dc[c.td].present || !ac[c.ta].present) fail(RRT_ERR_PARSE, "Cannot decode texture file: missing table");
+        for (int s = 0; s < layout.n_slots; s++) { layout.dct[s] = &dc[comps[layout.comp_of[s]].td]; layout.act[s] = &ac[comps[layout.comp_of[s]].ta]; }
+        // on several threads when the scan is long and has no restart markers (entropy_parallel above); one block after the other otherwise, and
+        // whenever that attempt declines
+        in_parallel = !restart_interval && !std::getenv("RRT_JPEG_SERIAL") && entropy_parallel(p, end, layout, (int)nc, n_stream, parts, block_ptr);
+        if (!in_parallel) {
+            parts.clear();
+            coef.assign(n_stream * 64, 0);
+            block_ptr.resize(n_stream);
+            for (size_t g = 0; g < n_stream; g++) block_ptr[g] = &coef[g * 64];
+            BitReader br{p, end};
+            int to_restart = restart_interval;
+            size_t g = 0;
+            for (size_t m = 0; m < (size_t)mcus_x * mcus_y; m++) {
+                restart_if_due(br, to_restart, nullptr);
+                for (int s = 0; s < layout.n_slots; s++, g++) {
+                    Component& c = comps[layout.comp_of[s]];
+                    int diff = 0;
+                    if (const int e = decode_block(br, *layout.dct[s], *layout.act[s], diff, &coef[g * 64])) fail(RRT_ERR_PARSE, block_error_text(e));
+                    c.pred += diff;
+                    if (c.pred < -32768 || c.pred > 32767) fail(RRT_ERR_PARSE, "Cannot decode texture file: DC predictor out of range");
+                    coef[g * 64] = (int16_t)c.pred;
                 }
-                for (size_t ci = 0; ci < nc; ci++) {
-                    Component& c = comps[ci];
-                    int16_t* blk = &coef[(((size_t)by * bw + bx) * nc + ci) * 64];
+                if (restart_interval) to_restart--;
+            }
+        }
+    } else {
+        // several scans (progressive, or a sequential file with a scan per component): coefficient planes, one scan after the other, until EOI
+        for (auto& c : comps) c.coef.assign((size_t)c.bw * c.bh * 64, 0);
+        for (bool more = true; more; more = next_scan(sc, false)) {
+            if (progressive) {
+                if (sc.Ss > sc.Se || sc.Se > 63 || sc.Al > 13 || (sc.Ss == 0 && sc.Se != 0) || (sc.Ss > 0 && sc.ns != 1)) fail(RRT_ERR_PARSE, "Cannot decode texture file: bad progressive scan");
+            } else { sc.Ss = 0; sc.Se = 63; sc.Ah = sc.Al = 0; }
+            for (int k = 0; k < sc.ns; k++) {
+                const Component& c = comps[sc.ci[k]];
+                const bool need_dc = sc.Ss == 0 && sc.Ah == 0, need_ac = sc.Se > 0;
+                if ((need_dc && !dc[c.td].present) || (need_ac && !ac[c.ta].present)) fail(RRT_ERR_PARSE, "Cannot decode texture file: missing table");
+            }
+            for (auto& c : comps) c.pred = 0;
+            BitReader br{p, end};
+            ProgressiveState ps;
+            int to_restart = restart_interval;
+            auto block = [&](Component& c, uint32_t bx, uint32_t by) {
+                int16_t* blk = &c.coef[((size_t)by * c.bw + bx) * 64];
+                if (!progressive) {
                     int diff = 0;
                     if (const int e = decode_block(br, dc[c.td], ac[c.ta], diff, blk)) fail(RRT_ERR_PARSE, block_error_text(e));
                     c.pred += diff;
                     if (c.pred < -32768 || c.pred > 32767) fail(RRT_ERR_PARSE, "Cannot decode texture file: DC predictor out of range");
                     blk[0] = (int16_t)c.pred;
-                }
-                if (restart_interval) to_restart--;
+                } else if (sc.Ss == 0) { if (sc.Ah == 0) prog_dc_first(br, dc[c.td], c, sc.Al, blk); else prog_dc_refine(br, sc.Al, blk); }
+                else if (sc.Ah == 0) prog_ac_first(br, ac[c.ta], ps, sc.Ss, sc.Se, sc.Al, blk);
+                else prog_ac_refine(br, ac[c.ta], ps, sc.Ss, sc.Se, sc.Al, blk);
+            };
+            if (sc.ns == 1) {                                           // not interleaved: the component's own blocks, only those that hold image samples (T.81 A.2.2)
+                Component& c = comps[sc.ci[0]];
+                const uint32_t nbx = (c.w + 7) / 8, nby = (c.hgt + 7) / 8;
+                for (uint32_t by = 0; by < nby; by++)
+                    for (uint32_t bx = 0; bx < nbx; bx++) { restart_if_due(br, to_restart, &ps); block(c, bx, by); if (restart_interval) to_restart--; }
+            } else {
+                for (uint32_t my = 0; my < mcus_y; my++)
+                    for (uint32_t mx = 0; mx < mcus_x; mx++) {
+                        restart_if_due(br, to_restart, &ps);
+                        for (int k = 0; k < sc.ns; k++) {
+                            Component& c = comps[sc.ci[k]];
+                            for (int sy = 0; sy < c.v; sy++) for (int sx = 0; sx < c.h; sx++) block(c, mx * c.h + sx, my * c.v + sy);
+                        }
+                        if (restart_interval) to_restart--;
+                    }
             }
+            p = br.p;                                                    // the reader never passes a marker: the next one is at or after this
         }
     }
+    auto block_of = [&](size_t ci, uint32_t bx, uint32_t by) -> const int16_t* {
+        const Component& c = comps[ci];
+        if (!one_scan) return &c.coef[((size_t)by * c.bw + bx) * 64];
+        const size_t m = (size_t)(by / c.v) * mcus_x + bx / c.h;
+        return block_ptr[m * layout.n_slots + slot_base[ci] + (by % c.v) * c.h + bx % c.h];
+    };
 
-    // ---- phase 2, every row of blocks on its own: dequantise, inverse DCT, colour conversion (a 1024 x 1024 texture: 3 x 16 384 blocks -- the larger
-    // part of the decode, and the part the host's cores can share)
+    // ---- phase 2: dequantise + inverse DCT into a sample plane per component (padded to whole blocks), every row of blocks on its own ...
     const auto t_entropy = std::chrono::steady_clock::now();
     const bool grey = nc == 1;
     channels = grey ? 1 : 3; out.resize((size_t)W * H * channels);
+    std::vector<std::unique_ptr<uint8_t[]>> plane(nc);
+    std::vector<size_t> row_first(nc + 1, 0);                           // block rows of all components, end to end
+    for (size_t c = 0; c < nc; c++) { plane[c].reset(new uint8_t[(size_t)comps[c].bw * 8 * comps[c].bh * 8 + 16]); row_first[c + 1] = row_first[c] + comps[c].bh; }
+    parallel_ranges(row_first[nc], 2, [&](size_t rb, size_t re, size_t) {
+        for (size_t r = rb; r < re; r++) {
+            size_t ci = 0; while (r >= row_first[ci + 1]) ci++;
+            const Component& c = comps[ci];
+            const uint32_t by = (uint32_t)(r - row_first[ci]);
+            const size_t stride = (size_t)c.bw * 8;
+            const uint16_t* t = qt[c.tq];
+            for (uint32_t bx = 0; bx < c.bw; bx++) {
+                const int16_t* q = block_of(ci, bx, by);
+                int32_t blk[64];
+                for (int k = 0; k < 64; k++) { const int32_t v = (int32_t)q[k] * t[k]; blk[k] = v < -(1 << 15) ? -(1 << 15) : v > (1 << 15) ? (1 << 15) : v; }   // hostile tables: keep the IDCT inside int32 (a valid file never gets near)
+                idct_islow(blk, plane[ci].get() + (size_t)by * 8 * stride + (size_t)bx * 8, stride);
+            }
+        }
+    });
+    // ... then chroma upsampling (libjpeg's triangle filters; the rows above the first and below the last are those rows again, jdmainct.c) and the
+    // colour conversion, every pixel row on its own
     const bool ycc = adobe_transform < 0 ? !(!grey && comps[0].id == 'R' && comps[1].id == 'G' && comps[2].id == 'B') : adobe_transform != 0;
     // IJG jdcolor.c: 16.16 fixed point, FIX(x) = (int)(x*65536 + 0.5)
     constexpr int32_t ONE_HALF = 1 << 15, F1_402 = 91881, F1_772 = 116130, F0_714 = 46802, F0_344 = 22554;
-    parallel_ranges(bh, 4, [&](size_t rb, size_t re, size_t) {
-        std::vector<uint8_t> rows(nc * 8 * stride);                      // the 8 pixel rows of one row of blocks, per component
-        for (size_t by = rb; by < re; by++) {
-            for (uint32_t bx = 0; bx < bw; bx++)
-                for (size_t ci = 0; ci < nc; ci++) {
-                    const int16_t* q = block_ptr[(by * bw + bx) * nc + ci];
-                    const uint16_t* t = qt[comps[ci].tq];
-                    int32_t blk[64];
-                    for (int k = 0; k < 64; k++) { const int32_t v = (int32_t)q[k] * t[k]; blk[k] = v < -(1 << 15) ? -(1 << 15) : v > (1 << 15) ? (1 << 15) : v; }   // hostile tables: keep the IDCT inside int32 (a valid file never gets near)
-                    idct_islow(blk, rows.data() + ci * 8 * stride + (size_t)bx * 8, stride);
+    parallel_ranges(H, 16, [&](size_t yb, size_t ye, size_t) {
+        std::vector<uint8_t> tmp[3];
+        for (size_t c = 1; c < nc; c++) tmp[c].resize((size_t)comps[c].w * 2 + 8);
+        for (size_t y = yb; y < ye; y++) {
+            const uint8_t* row[3] = {nullptr, nullptr, nullptr};
+            for (size_t ci = 0; ci < nc; ci++) {
+                const Component& c = comps[ci];
+                const size_t stride = (size_t)c.bw * 8;
+                const uint8_t* base = plane[ci].get();
+                if (c.h == hmax && c.v == vmax) row[ci] = base + y * stride;
+                else if (c.w <= 2) {                                     // jdsample.c uses the triangle filters for components wider than two samples only: else replication
+                    const uint8_t* in = base + (c.v == vmax ? y : y / 2) * stride;
+                    for (uint32_t x = 0; x < 2 * c.w; x++) tmp[ci][x] = in[x / 2];
+                    row[ci] = tmp[ci].data();
                 }
-            for (uint32_t r = 0; r < 8; r++) {
-                const size_t y = by * 8 + r;
-                if (y >= H) break;
-                const uint8_t* Y = rows.data() + r * stride;
-                if (grey) { std::memcpy(out.data() + y * W, Y, W); continue; }
-                const uint8_t* Cb = rows.data() + (8 + r) * stride; const uint8_t* Cr = rows.data() + (16 + r) * stride;
-                uint8_t* o = out.data() + y * W * 3;
-                for (uint32_t x = 0; x < W; x++) {
-                    if (!ycc) { o[3 * x] = Y[x]; o[3 * x + 1] = Cb[x]; o[3 * x + 2] = Cr[x]; continue; }
-                    int32_t yy = Y[x], cb = Cb[x] - 128, cr = Cr[x] - 128;
-                    int32_t rr = yy + ((F1_402 * cr + ONE_HALF) >> 16);
-                    int32_t g = yy + ((-F0_344 * cb + ONE_HALF - F0_714 * cr) >> 16);
-                    int32_t b = yy + ((F1_772 * cb + ONE_HALF) >> 16);
-                    o[3 * x] = clamp255(rr); o[3 * x + 1] = clamp255(g); o[3 * x + 2] = clamp255(b);
+                else if (c.v == vmax) { upsample_h2v1(base + y * stride, c.w, tmp[ci].data()); row[ci] = tmp[ci].data(); }
+                else {
+                    const size_t r = y / 2;
+                    const size_t far = (y & 1) ? std::min<size_t>(r + 1, c.hgt - 1) : (r ? r - 1 : 0);
+                    upsample_h2v2(base + r * stride, base + far * stride, c.w, tmp[ci].data()); row[ci] = tmp[ci].data();
                 }
+            }
+            if (grey) { std::memcpy(out.data() + y * W, row[0], W); continue; }
+            const uint8_t* Y = row[0]; const uint8_t* Cb = row[1]; const uint8_t* Cr = row[2];
+            uint8_t* o = out.data() + y * W * 3;
+            for (uint32_t x = 0; x < W; x++) {
+                if (!ycc) { o[3 * x] = Y[x]; o[3 * x + 1] = Cb[x]; o[3 * x + 2] = Cr[x]; continue; }
+                int32_t yy = Y[x], cb = Cb[x] - 128, cr = Cr[x] - 128;
+                int32_t rr = yy + ((F1_402 * cr + ONE_HALF) >> 16);
+                int32_t g = yy + ((-F0_344 * cb + ONE_HALF - F0_714 * cr) >> 16);
+                int32_t b = yy + ((F1_772 * cb + ONE_HALF) >> 16);
+                o[3 * x] = clamp255(rr); o[3 * x + 1] = clamp255(g); o[3 * x + 2] = clamp255(b);
             }
         }
     });
     if (trace) {
         const auto t_end = std::chrono::steady_clock::now();
-        fprintf(stderr, "[jpeg] %u x %u, %zu bytes: entropy decode %.2f ms (%zu threads), dequantise + IDCT + colour %.2f ms\n", W, H, buf.size(),
+        fprintf(stderr, "[jpeg] %u x %u, %zu bytes%s: entropy decode %.2f ms (%zu threads), dequantise + IDCT + upsampling + colour %.2f ms\n", W, H, buf.size(), progressive ? ", progressive" : "",
                 std::chrono::duration<double, std::milli>(t_entropy - t_begin).count(), in_parallel ? parts.size() : (size_t)1, std::chrono::duration<double, std::milli>(t_end - t_entropy).count());
     }
 }

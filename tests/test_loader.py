@@ -221,6 +221,50 @@ def test_jpeg_entropy_decode_on_several_threads(rrt, tmp_path, monkeypatch):
             assert np.array_equal(rrt.decode_image_file(str(t)), want), (cut, part)
 
 
+def test_jpeg_subsampled_progressive_and_multi_scan_files(rrt, tmp_path, monkeypatch):
+    """What the reference's `image` crate decodes and most JPEGs in the wild are: 4:2:2 and 4:2:0 chroma (libjpeg's triangle-filter upsampling, replication
+    for components of one or two columns, edge rows repeated), progressive frames (DC/AC first and refinement scans, end-of-band runs) and restart markers in
+    all of them -- bit-equal to libjpeg (PIL) over sizes with partial MCUs, one-pixel rows and columns, qualities 5..100; the interleaved sequential ones also
+    through the many-threads entropy decode with a 4:2:0 MCU of six blocks."""
+    Image = pytest.importorskip("PIL.Image")
+    import itertools
+    rng = np.random.default_rng(3)
+    def smooth(h, w): return np.clip(np.cumsum(rng.normal(size=(h, w, 3)), axis=1) * 6 + 128, 0, 255).astype(np.uint8)
+    imgs = {"s67x131": smooth(67, 131), "n40x24": rng.integers(0, 256, (40, 24, 3), dtype=np.uint8), "s8x8": smooth(8, 8), "s1x1": smooth(1, 1), "n9x17": rng.integers(0, 256, (9, 17, 3), dtype=np.uint8),
+            "s16x16": smooth(16, 16), "s17x33": smooth(17, 33), "s2x2": smooth(2, 2), "s1x5": smooth(1, 5), "s5x1": smooth(5, 1), "s3x4": smooth(3, 4), "s6x5": smooth(6, 5), "s300x200": smooth(300, 200)}
+    monkeypatch.setenv("RRT_HOST_THREADS", "8")
+    n = 0
+    for (name, img), q, sub, prog, extra in itertools.product(imgs.items(), (5, 60, 95, 100), (0, 1, 2), (False, True), ({}, {"restart_marker_blocks": 3}, {"restart_marker_rows": 1})):
+        f = tmp_path / "t.jpg"
+        try:
+            Image.fromarray(img).save(f, quality=q, subsampling=sub, progressive=prog, **extra)
+        except (TypeError, OSError):
+            continue                                                    # an older Pillow without restart-marker options / an encoder that refuses the combination
+        ref = np.asarray(Image.open(f).convert("RGB"))
+        for part in (None, "40"):                                       # one thread; parts of 40 bytes on the pool (one-scan sequential files without restart markers)
+            if part: monkeypatch.setenv("RRT_JPEG_PART_BYTES", part)
+            else: monkeypatch.delenv("RRT_JPEG_PART_BYTES", raising=False)
+            got = rrt.decode_image_file(str(f))
+            assert np.array_equal(got, ref), (name, q, sub, prog, extra, part, int(np.abs(got.astype(int) - ref).max()))
+        n += 1
+    assert n > 500
+    # a greyscale progressive file decodes (and is then refused by the RGB8 entry point, like the sequential one)
+    g = tmp_path / "grey.jpg"
+    Image.fromarray(imgs["s67x131"][..., 0]).save(g, quality=80, progressive=True)
+    with pytest.raises(rrt.RrtError) as e:
+        rrt.decode_image_file(str(g))
+    assert e.value.status == rrt.ERR_UNSUPPORTED
+    # truncated progressive / subsampled files: whatever scans are complete are shown, or a parse error; never a crash
+    Image.fromarray(imgs["s300x200"]).save(f, quality=80, subsampling=2, progressive=True)
+    data = open(f, "rb").read()
+    for cut in (len(data) // 4, len(data) // 2, len(data) - 5, 300, 40):
+        t = tmp_path / "cut.jpg"; t.write_bytes(data[:cut])
+        try:
+            assert rrt.decode_image_file(str(t)).shape == (300, 200, 3)
+        except rrt.RrtError as e2:
+            assert e2.status in (rrt.ERR_PARSE, rrt.ERR_UNSUPPORTED)
+
+
 @pytest.mark.timeout(240)
 def test_concurrent_loads_share_the_host_pool(rrt):
     """Several threads inside rrt_model_load_obj at once (ctypes drops the GIL): nested parallel ranges -- loader > texture prefetch > decoder > parts --
