@@ -1,5 +1,5 @@
 // image_decode.cpp -- build-owned texture decode: Huffman JPEG (8-bit; sequential or progressive; 4:4:4, 4:2:2, 4:2:0 or greyscale; one scan
-// or many; restart markers) and non-interlaced 8-bit PNG.  Stands where the reference calls the `image` crate
+// or many; restart markers) and PNG (8-bit samples or 1-8-bit palette, interlaced or not).  Stands where the reference calls the `image` crate
 // (`ImageReader::open(..).decode()`, src/file_management/utils.rs:345-350; image 0.25.9 -> zune-jpeg 0.5.8 / png 0.18.0,
 // Cargo.lock).  Those crates are not in the reference tree, JPEG decoders are not bit-identical to one another and no
 // reference test pins decoded texels, so parity at this boundary is UNPINNED: the hot path's input is
@@ -692,29 +692,61 @@ void decode_png(const std::vector<uint8_t>& buf, std::vector<uint8_t>& out, uint
     }
     if (ctype < 0 || W == 0 || H == 0) fail(RRT_ERR_PARSE, "Cannot decode texture file: bad PNG header");
     if (W > kMaxImageDim || H > kMaxImageDim) fail(RRT_ERR_PARSE, "Cannot decode texture file: PNG dimensions beyond the supported 65535 x 65535");   // (row+1)*H below must not wrap
-    if (depth != 8 || interlace != 0 || trns) fail(RRT_ERR_UNSUPPORTED, "PNG: only 8-bit, non-interlaced, no tRNS");
-    int src_ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    if (trns || depth == 16) fail(RRT_ERR_UNSUPPORTED, "PNG: 16-bit samples and tRNS transparency are not supported");   // (neither decodes to 3 bytes per pixel in the `image` crate)
+    const int src_ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!src_ch) fail(RRT_ERR_PARSE, "Cannot decode texture file: bad PNG colour type");
-    const size_t row = (size_t)W * src_ch;
-    std::vector<uint8_t> raw((row + 1) * H);
+    const bool depth_ok = depth == 8 || ((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4));
+    if (!depth_ok || interlace > 1) fail(RRT_ERR_PARSE, "Cannot decode texture file: bad PNG header");
+    // one sub-image per pass (Adam7: seven, each a lattice of the picture; else the picture itself), every one filtered on its own (PNG spec 8.2, 9)
+    struct Pass { uint32_t x0, y0, dx, dy; };
+    static const Pass kAdam7[7] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+    static const Pass kWhole = {0, 0, 1, 1};
+    const int n_pass = interlace ? 7 : 1;
+    const size_t bpp = std::max<size_t>(1, (size_t)src_ch * depth / 8);                       // filter distance in bytes
+    auto pass_dims = [&](const Pass& P, uint32_t& pw, uint32_t& ph) { pw = W > P.x0 ? (W - P.x0 + P.dx - 1) / P.dx : 0; ph = H > P.y0 ? (H - P.y0 + P.dy - 1) / P.dy : 0; };
+    size_t raw_total = 0;
+    for (int k = 0; k < n_pass; k++) {
+        uint32_t pw, ph; pass_dims(interlace ? kAdam7[k] : kWhole, pw, ph);
+        if (pw && ph) raw_total += (((size_t)pw * src_ch * depth + 7) / 8 + 1) * ph;
+    }
+    std::vector<uint8_t> raw(raw_total);
     uLongf raw_len = (uLongf)raw.size();
     if (uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) != Z_OK || raw_len != raw.size()) fail(RRT_ERR_PARSE, "Cannot decode texture file: PNG inflate failed");
-    std::vector<uint8_t> img(row * H);
-    for (uint32_t y = 0; y < H; y++) {
-        const uint8_t ft = raw[(row + 1) * y]; const uint8_t* s = &raw[(row + 1) * y + 1];
-        uint8_t* o = &img[row * y]; const uint8_t* up = y ? &img[row * (y - 1)] : nullptr;
-        for (size_t x = 0; x < row; x++) {
-            int a = x >= (size_t)src_ch ? o[x - src_ch] : 0, b = up ? up[x] : 0, c = (up && x >= (size_t)src_ch) ? up[x - src_ch] : 0;
-            int pred = 0;
-            switch (ft) {
-                case 0: pred = 0; break;
-                case 1: pred = a; break;
-                case 2: pred = b; break;
-                case 3: pred = (a + b) >> 1; break;
-                case 4: { int pp = a + b - c, pa = std::abs(pp - a), pb = std::abs(pp - b), pc = std::abs(pp - c); pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); break; }
-                default: fail(RRT_ERR_PARSE, "Cannot decode texture file: bad PNG filter");
+    std::vector<uint8_t> img((size_t)W * H * src_ch);                                         // one byte per sample
+    const int maxval = (1 << depth) - 1;
+    size_t at = 0;
+    std::vector<uint8_t> prev, cur;
+    for (int k = 0; k < n_pass; k++) {
+        const Pass& P = interlace ? kAdam7[k] : kWhole;
+        uint32_t pw, ph; pass_dims(P, pw, ph);
+        if (!pw || !ph) continue;
+        const size_t row = ((size_t)pw * src_ch * depth + 7) / 8;
+        prev.assign(row, 0); cur.assign(row, 0);
+        for (uint32_t y = 0; y < ph; y++) {
+            const uint8_t ft = raw[at]; const uint8_t* sline = &raw[at + 1]; at += row + 1;
+            for (size_t x = 0; x < row; x++) {
+                const int a = x >= bpp ? cur[x - bpp] : 0, b = prev[x], c = x >= bpp ? prev[x - bpp] : 0;
+                int pred = 0;
+                switch (ft) {
+                    case 0: pred = 0; break;
+                    case 1: pred = a; break;
+                    case 2: pred = b; break;
+                    case 3: pred = (a + b) >> 1; break;
+                    case 4: { int pp = a + b - c, pa = std::abs(pp - a), pb = std::abs(pp - b), pc = std::abs(pp - c); pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); break; }
+                    default: fail(RRT_ERR_PARSE, "Cannot decode texture file: bad PNG filter");
+                }
+                cur[x] = (uint8_t)(sline[x] + pred);
             }
-            o[x] = (uint8_t)(s[x] + pred);
+            uint8_t* orow = &img[((size_t)(P.y0 + (size_t)y * P.dy) * W) * src_ch];
+            for (uint32_t x = 0; x < pw; x++) {
+                uint8_t* o = orow + ((size_t)P.x0 + (size_t)x * P.dx) * src_ch;
+                if (depth == 8) for (int q = 0; q < src_ch; q++) o[q] = cur[(size_t)x * src_ch + q];
+                else {                                                                       // 1, 2, 4 bits: one channel, most significant bits first
+                    const int v = (cur[((size_t)x * depth) >> 3] >> (8 - depth - (((size_t)x * depth) & 7))) & maxval;
+                    o[0] = ctype == 3 ? (uint8_t)v : (uint8_t)(v * 255 / maxval);             // palette indices as they are, grey levels scaled to 8 bits
+                }
+            }
+            prev.swap(cur);
         }
     }
     if (ctype == 3) {                                    // indexed -> Rgb8, as the `image` crate expands palettes

@@ -303,6 +303,28 @@ def test_png_decoder(rrt, tmp_path):
     assert np.array_equal(rrt.decode_image_file(str(tmp_path / "p.png")), np.asarray(Image.open(tmp_path / "p.png").convert("RGB")))
 
 
+def test_png_interlaced_and_low_bit_depth(rrt, tmp_path):
+    """Adam7-interlaced files (seven sub-images, each filtered on its own; passes that are empty for small pictures) and 1/2/4-bit palettes, against PIL,
+    from 1 x 1 up; 16-bit samples and tRNS are refused (they do not decode to 3 bytes per pixel in the reference's `image` crate either)."""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(21)
+    for h, w in ((1, 1), (1, 9), (9, 1), (2, 3), (5, 5), (8, 8), (9, 17), (37, 53), (64, 64)):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        for interlace in (False, True):
+            p = tmp_path / "a.png"
+            Image.fromarray(img).save(p, interlace=interlace)
+            assert np.array_equal(rrt.decode_image_file(str(p)), img), (h, w, interlace)
+            for colors in (2, 4, 16, 200):
+                q = Image.fromarray(img).quantize(colors)
+                q.save(p, interlace=interlace, bits={2: 1, 4: 2, 16: 4, 200: 8}[colors])
+                assert np.array_equal(rrt.decode_image_file(str(p)), np.asarray(Image.open(p).convert("RGB"))), (h, w, interlace, colors)
+    p = tmp_path / "deep.png"
+    Image.fromarray((rng.integers(0, 65536, (8, 8), dtype=np.uint16))).save(p)
+    with pytest.raises(rrt.RrtError) as e:
+        rrt.decode_image_file(str(p))
+    assert e.value.status == rrt.ERR_UNSUPPORTED
+
+
 def _write(tmp_path, obj_text, mtl_text="newmtl m\nKa 1 1 1\nmap_Ka t.png\n"):
     Image = pytest.importorskip("PIL.Image")
     Image.fromarray(np.full((2, 2, 3), 128, np.uint8)).save(tmp_path / "t.png")
