@@ -165,6 +165,10 @@ FrameParams frame_params(const rrt_raytracer* rt, uint32_t width, uint32_t heigh
     f.tiles_x = (width + 7) / 8; f.tiles_y = (height + 7) / 8;
     f.rank = rank; f.world = world; f.tiled_output = tiled ? 1u : 0u;
     f.tile_begin = 0; f.tile_end = f.tiles_x * f.tiles_y; f.row_begin = 0; f.row_end = height;
+    // XCD-aware block order (render.hip): worth 2-4 % where the scene is far larger than an XCD's L2 (100 k / 1 M-triangle soups), costs 4 % on the teapot
+    // (profiles/r03_xcd_chunk_sweep.txt; chunks as 64 x 64-pixel squares instead of 512 x 8 strips: 1 % slower again): on for scenes of 50 000 triangle slots and more.
+    static const int forced = [] { const char* e = std::getenv("RRT_XCD_CHUNK"); return e ? std::atoi(e) : -1; }();
+    f.xcd_chunk = forced >= 0 ? (uint32_t)forced : (rt->scene.n_slots >= 50000u ? 256u : 0u);
     return f;
 }
 

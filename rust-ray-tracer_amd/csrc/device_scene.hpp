@@ -97,7 +97,8 @@ struct FrameParams {
     double x_scale, y_scale, z_value;   // engine.rs:189-191
     uint32_t tiles_x, tiles_y;   // 8x8-pixel tiles covering the canvas
     uint32_t rank, world;        // tile k belongs to rank k % world
-    uint32_t tiled_output, _pad; // 0: out is the row-major framebuffer; 1: out is this rank's tile-major buffer
+    uint32_t tiled_output;       // 0: out is the row-major framebuffer; 1: out is this rank's tile-major buffer
+    uint32_t xcd_chunk;          // blocks per chunk of the XCD-aware block order (render.hip: render_kernel), 0 = plain order
     // A launch may cover a band of the frame only (progressive display, engine.rs:196-253): the tiles [tile_begin, tile_end) in row-major tile
     // order, and of those only the canvas rows [row_begin, row_end).  The whole frame: tile_begin = 0, tile_end = tiles_x*tiles_y, rows [0, height).
     uint32_t tile_begin, tile_end, row_begin, row_end;

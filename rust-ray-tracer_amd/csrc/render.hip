@@ -1544,9 +1544,16 @@ __global__ __launch_bounds__(64, kWalk == kWalkBundle ? RRT_WAVES_BUNDLE : kWalk
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const uint32_t lane = threadIdx.x;
     const Stack stk{lds + kParkBytes, lane};
-    const uint32_t local_tile = blockIdx.x >> 2, quad = blockIdx.x & 3u;
-    const uint32_t tile = F.tile_begin + local_tile * F.world + F.rank;
+    // Blocks that share an XCD (equal blockIdx % 8 under the observed round-robin placement: a speed matter only) take whole chunks of consecutive tiles, so that
+    // an XCD's 4 MB L2 serves one screen region's part of a large scene at a time instead of all of it (F.xcd_chunk blocks per chunk, 0 = off; api.cpp decides).
+    uint32_t blk = blockIdx.x;
+    if (F.xcd_chunk) {
+        const uint32_t C = F.xcd_chunk, full = (gridDim.x / (8u * C)) * (8u * C);
+        if (blk < full) { const uint32_t xcd = blk & 7u, i = blk >> 3; blk = ((i / C) * 8u + xcd) * C + (i % C); }
+    }
+    const uint32_t local_tile = blk >> 2, quad = blk & 3u;
     const uint32_t pix = lane >> 2, sub = lane & 3u;
+    const uint32_t tile = F.tile_begin + local_tile * F.world + F.rank;
     const bool tile_ok = tile < F.tile_end;
     const uint32_t tx = tile_ok ? tile % F.tiles_x : 0, ty = tile_ok ? tile / F.tiles_x : 0;
 #if RRT_WAVE_FOOTPRINT == 1        // 8 x 2 pixels per wave (experiment: 32-byte row segments instead of 16)
