@@ -1576,9 +1576,21 @@ __global__ __launch_bounds__(64, kWalk == kWalkBundle ? RRT_WAVES_BUNDLE : kWalk
     const V3 dir = mk(xd * F.x_scale, yd * F.y_scale, F.z_value);
 #ifdef RRT_PROFILE
     Prof prof{}; prof.last = __builtin_amdgcn_s_memtime();
+    const unsigned long long wave_rt0 = __builtin_amdgcn_s_memrealtime(); (void)wave_rt0;
 #endif
     const uint32_t c = trace_colour<kWalk, kGroups>(PROF_ARG S, stk, traced, ld3(S.origin), dir);
-#ifdef RRT_PROFILE
+#if defined(RRT_PROFILE) && defined(RRT_PROF_WAVETIME)
+#ifndef RRT_MEMTIME_TICKS_PER_US
+#define RRT_MEMTIME_TICKS_PER_US 100ull
+#endif
+    {   // developer build: how long each wave lived (s_memrealtime: the constant 100 MHz clock; s_memtime counts shader cycles), one count per wave into
+        // power-of-two buckets of microseconds, the longest in slot 16
+        const unsigned long long ticks = __builtin_amdgcn_s_memrealtime() - wave_rt0;
+        const uint32_t us = (uint32_t)(ticks / RRT_MEMTIME_TICKS_PER_US);
+        const uint32_t bucket = us < 2u ? 0u : (uint32_t)(31 - __builtin_clz(us));                 // 0: < 2 us, b: [2^b, 2^(b+1)) us
+        if (lane == 0) { atomicAdd(S.prof + (bucket < 15u ? bucket : 15u), 1ull); atomicMax(S.prof + 16, ticks); }
+    }
+#elif defined(RRT_PROFILE)
     PROF_T(4);
     for (int i = 0; i < 16; i++) if (prof.c[i]) atomicAdd(S.prof + i, prof.c[i]);
     if (lane == 0) { for (int i = 0; i < 8; i++) if (prof.t[i]) atomicAdd(S.prof + 16 + i, prof.t[i]); }
