@@ -78,7 +78,8 @@ template <class F> int guarded(F&& f) {
     catch (...) { set_error_detail("unknown failure"); return RRT_ERR_INVALID_ARG; }
 }
 
-// The HIP context and this library's code object come up lazily, at the first HIP call that needs them (~90 ms on a fresh process).  A model is
+// The HIP runtime, the process's first queue and this library's code object come up lazily, at the first HIP call that needs them (160-240 ms on a fresh
+// process: runtime start 60-95, first queue 80-140, page-locked ring 13; RRT_SETUP_TRACE prints them).  A model is
 // always loaded before a raytracer is created, so the loaders start that work on a helper thread and rrt_raytracer_create finds it done.
 struct DeviceWarmer {
     std::thread th; std::once_flag once; std::mutex mu; bool joined = false;
@@ -93,17 +94,30 @@ struct DeviceWarmer {
     void start() {
         std::call_once(once, [this] {
             th = std::thread([] {
+                const bool trace = std::getenv("RRT_SETUP_TRACE") != nullptr;
+                auto lap = [trace, last = std::chrono::steady_clock::now()](const char* what) mutable {
+                    if (!trace) return;
+                    const auto now = std::chrono::steady_clock::now();
+                    fprintf(stderr, "[warm-up]    %-34s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count()); last = now;
+                };
                 int n = 0;
                 if (hipGetDeviceCount(&n) != hipSuccess || n == 0) { (void)hipGetLastError(); return; }
+                lap("hipGetDeviceCount (runtime start)");
                 const int dev = hinted_device(n);
                 if (dev >= 0 && hipSetDevice(dev) == hipSuccess && hipFree(nullptr) == hipSuccess) {
+                    lap("hipSetDevice + hipFree(0) (context)");
                     void* p = nullptr; char probe[256] = {};
                     if (hipMalloc(&p, 1 << 20) == hipSuccess) {           // the first allocation and the first host-to-device copy of a process set up the
-                        (void)hipMemcpy(p, probe, sizeof probe, hipMemcpyHostToDevice);   // runtime's memory pools and staging buffers (~80 ms), whoever issues them
+                        lap("first hipMalloc");
+                        (void)hipMemcpy(p, probe, sizeof probe, hipMemcpyHostToDevice);   // the process's first queue (80-140 ms, whoever causes it: without this copy the first stream pays it)
+                        lap("first hipMemcpy (pageable)");
                         (void)hipFree(p);
                     }
+                    lap("first hipFree");
                     preload_kernels();
+                    lap("code object (preload_kernels)");
                     staged_upload_warm();                                 // the pinned staging ring of the set-up uploads (scene_build.hip)
+                    lap("pinned ring + set-up streams");
                 }
                 (void)hipGetLastError();
             });
