@@ -602,10 +602,52 @@ void decode_jpeg(const std::vector<uint8_t>& buf, std::vector<uint8_t>& out, uin
         return block_ptr[m * layout.n_slots + slot_base[ci] + (by % c.v) * c.h + bx % c.h];
     };
 
-    // ---- phase 2: dequantise + inverse DCT into a sample plane per component (padded to whole blocks), every row of blocks on its own ...
+    // ---- phase 2: dequantise + inverse DCT + (upsampling +) colour conversion; subsampled files via a sample plane per component (padded to whole blocks)
     const auto t_entropy = std::chrono::steady_clock::now();
     const bool grey = nc == 1;
     channels = grey ? 1 : 3; out.resize((size_t)W * H * channels);
+    const bool ycc = adobe_transform < 0 ? !(!grey && comps[0].id == 'R' && comps[1].id == 'G' && comps[2].id == 'B') : adobe_transform != 0;
+    // IJG jdcolor.c: 16.16 fixed point, FIX(x) = (int)(x*65536 + 0.5)
+    constexpr int32_t ONE_HALF = 1 << 15, F1_402 = 91881, F1_772 = 116130, F0_714 = 46802, F0_344 = 22554;
+    auto convert_row = [&](const uint8_t* Y, const uint8_t* Cb, const uint8_t* Cr, uint8_t* o) {
+        for (uint32_t x = 0; x < W; x++) {
+            if (!ycc) { o[3 * x] = Y[x]; o[3 * x + 1] = Cb[x]; o[3 * x + 2] = Cr[x]; continue; }
+            int32_t yy = Y[x], cb = Cb[x] - 128, cr = Cr[x] - 128;
+            int32_t rr = yy + ((F1_402 * cr + ONE_HALF) >> 16);
+            int32_t g = yy + ((-F0_344 * cb + ONE_HALF - F0_714 * cr) >> 16);
+            int32_t b = yy + ((F1_772 * cb + ONE_HALF) >> 16);
+            o[3 * x] = clamp255(rr); o[3 * x + 1] = clamp255(g); o[3 * x + 2] = clamp255(b);
+        }
+    };
+    auto idct_block = [&](size_t ci, uint32_t bx, uint32_t by, uint8_t* dst, size_t stride) {
+        const int16_t* q = block_of(ci, bx, by);
+        const uint16_t* t = qt[comps[ci].tq];
+        int32_t blk[64];
+        for (int k = 0; k < 64; k++) { const int32_t v = (int32_t)q[k] * t[k]; blk[k] = v < -(1 << 15) ? -(1 << 15) : v > (1 << 15) ? (1 << 15) : v; }   // hostile tables: keep the IDCT inside int32 (a valid file never gets near)
+        idct_islow(blk, dst, stride);
+    };
+    bool full_res = true;
+    for (auto& c : comps) full_res = full_res && c.h == hmax && c.v == vmax;
+    if (full_res) {
+        // every component at full resolution (the scene's textures): a row of blocks at a time through a small buffer of the worker's own, converted at
+        // once -- whole sample planes would be 3 MB of freshly mapped pages per texture, faulted in by a hundred threads at the same moment
+        const uint32_t bw = comps[0].bw, bh = comps[0].bh;
+        const size_t stride = (size_t)bw * 8;
+        parallel_ranges(bh, 4, [&](size_t rb, size_t re, size_t) {
+            std::vector<uint8_t> rows(nc * 8 * stride);
+            for (size_t by = rb; by < re; by++) {
+                for (uint32_t bx = 0; bx < bw; bx++)
+                    for (size_t ci = 0; ci < nc; ci++) idct_block(ci, bx, (uint32_t)by, rows.data() + ci * 8 * stride + (size_t)bx * 8, stride);
+                for (uint32_t r = 0; r < 8; r++) {
+                    const size_t y = by * 8 + r;
+                    if (y >= H) break;
+                    const uint8_t* Y = rows.data() + r * stride;
+                    if (grey) std::memcpy(out.data() + y * W, Y, W);
+                    else convert_row(Y, rows.data() + (8 + r) * stride, rows.data() + (16 + r) * stride, out.data() + y * W * 3);
+                }
+            }
+        });
+    } else {
     std::vector<std::unique_ptr<uint8_t[]>> plane(nc);
     std::vector<size_t> row_first(nc + 1, 0);                           // block rows of all components, end to end
     for (size_t c = 0; c < nc; c++) { plane[c].reset(new uint8_t[(size_t)comps[c].bw * 8 * comps[c].bh * 8 + 16]); row_first[c + 1] = row_first[c] + comps[c].bh; }
@@ -615,20 +657,11 @@ void decode_jpeg(const std::vector<uint8_t>& buf, std::vector<uint8_t>& out, uin
             const Component& c = comps[ci];
             const uint32_t by = (uint32_t)(r - row_first[ci]);
             const size_t stride = (size_t)c.bw * 8;
-            const uint16_t* t = qt[c.tq];
-            for (uint32_t bx = 0; bx < c.bw; bx++) {
-                const int16_t* q = block_of(ci, bx, by);
-                int32_t blk[64];
-                for (int k = 0; k < 64; k++) { const int32_t v = (int32_t)q[k] * t[k]; blk[k] = v < -(1 << 15) ? -(1 << 15) : v > (1 << 15) ? (1 << 15) : v; }   // hostile tables: keep the IDCT inside int32 (a valid file never gets near)
-                idct_islow(blk, plane[ci].get() + (size_t)by * 8 * stride + (size_t)bx * 8, stride);
-            }
+            for (uint32_t bx = 0; bx < c.bw; bx++) idct_block(ci, bx, by, plane[ci].get() + (size_t)by * 8 * stride + (size_t)bx * 8, stride);
         }
     });
     // ... then chroma upsampling (libjpeg's triangle filters; the rows above the first and below the last are those rows again, jdmainct.c) and the
     // colour conversion, every pixel row on its own
-    const bool ycc = adobe_transform < 0 ? !(!grey && comps[0].id == 'R' && comps[1].id == 'G' && comps[2].id == 'B') : adobe_transform != 0;
-    // IJG jdcolor.c: 16.16 fixed point, FIX(x) = (int)(x*65536 + 0.5)
-    constexpr int32_t ONE_HALF = 1 << 15, F1_402 = 91881, F1_772 = 116130, F0_714 = 46802, F0_344 = 22554;
     parallel_ranges(H, 16, [&](size_t yb, size_t ye, size_t) {
         std::vector<uint8_t> tmp[3];
         for (size_t c = 1; c < nc; c++) tmp[c].resize((size_t)comps[c].w * 2 + 8);
@@ -651,19 +684,10 @@ void decode_jpeg(const std::vector<uint8_t>& buf, std::vector<uint8_t>& out, uin
                     upsample_h2v2(base + r * stride, base + far * stride, c.w, tmp[ci].data()); row[ci] = tmp[ci].data();
                 }
             }
-            if (grey) { std::memcpy(out.data() + y * W, row[0], W); continue; }
-            const uint8_t* Y = row[0]; const uint8_t* Cb = row[1]; const uint8_t* Cr = row[2];
-            uint8_t* o = out.data() + y * W * 3;
-            for (uint32_t x = 0; x < W; x++) {
-                if (!ycc) { o[3 * x] = Y[x]; o[3 * x + 1] = Cb[x]; o[3 * x + 2] = Cr[x]; continue; }
-                int32_t yy = Y[x], cb = Cb[x] - 128, cr = Cr[x] - 128;
-                int32_t rr = yy + ((F1_402 * cr + ONE_HALF) >> 16);
-                int32_t g = yy + ((-F0_344 * cb + ONE_HALF - F0_714 * cr) >> 16);
-                int32_t b = yy + ((F1_772 * cb + ONE_HALF) >> 16);
-                o[3 * x] = clamp255(rr); o[3 * x + 1] = clamp255(g); o[3 * x + 2] = clamp255(b);
-            }
+            convert_row(row[0], row[1], row[2], out.data() + y * W * 3);
         }
     });
+    }
     if (trace) {
         const auto t_end = std::chrono::steady_clock::now();
         fprintf(stderr, "[jpeg] %u x %u, %zu bytes%s: entropy decode %.2f ms (%zu threads), dequantise + IDCT + upsampling + colour %.2f ms\n", W, H, buf.size(), progressive ? ", progressive" : "",

@@ -45,9 +45,12 @@ public:
         {
             std::lock_guard<std::mutex> g(m_);
             q_.push_back(std::move(task));
-            spawn = starting_ == 0 && want_worker();                       // (at most one start in flight on the submitters' account: the workers grow the pool)
+            if (q_.size() > idle_ && n_workers_ < cap_) { n_workers_++; spawn = true; }   // (idle workers that have not woken yet are still counted: one each)
         }
-        if (spawn) start_worker();
+        if (spawn) {
+            try { std::thread([this] { work(); }).detach(); }
+            catch (...) { std::lock_guard<std::mutex> g(m_); n_workers_--; }         // no thread to be had: whoever waits for the work does it himself
+        }
         cv_.notify_one();
     }
 
@@ -59,30 +62,18 @@ private:
         return p;
     }
     HostPool() { const unsigned hc = std::thread::hardware_concurrency(); cap_ = std::max(1u, std::min(hc ? hc : 1u, 128u)); }
-    // (m_ held)  One more worker if more is queued than workers are idle -- idle workers that have not woken yet are still counted, one each.
-    bool want_worker() { if (q_.size() > idle_ + starting_ && n_workers_ < cap_) { n_workers_++; starting_++; return true; } return false; }
-    void start_worker() {
-        try { std::thread([this] { work(); }).detach(); }
-        catch (...) { std::lock_guard<std::mutex> g(m_); n_workers_--; starting_--; }   // no thread to be had: whoever waits for the work does it himself
-    }
-    // Creating a thread costs the creator 30-60 us, so a caller that offers 127 ranges must not create 127 workers before it starts on its own
-    // range: submit() starts at most one, and every worker, once running, starts another while more is queued than workers are free -- the pool
-    // doubles until it fits the demand.
     void work() {
         std::unique_lock<std::mutex> lk(m_);
-        starting_--;
         for (;;) {
             while (q_.empty()) { idle_++; cv_.wait(lk); idle_--; }
             std::function<void()> t = std::move(q_.front()); q_.pop_front();
-            const bool spawn = want_worker();
             lk.unlock();
-            if (spawn) start_worker();
             t();
             lk.lock();
         }
     }
     std::mutex m_; std::condition_variable cv_; std::deque<std::function<void()>> q_;
-    unsigned n_workers_ = 0, idle_ = 0, starting_ = 0, cap_ = 1;
+    unsigned n_workers_ = 0, idle_ = 0, cap_ = 1;
 };
 
 // f(begin, end, part) on `parts` contiguous ranges of [0, n); parts <= host_threads().  An exception of the EARLIEST range that threw is rethrown.
