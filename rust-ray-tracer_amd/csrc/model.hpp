@@ -1,6 +1,7 @@
 // model.hpp -- host-side scene IR of the MI355X hot path (SceneData, src/scene/scenedata.rs:5-13 of the reference).
 // Plain f64 everywhere, as the reference (src/scene/engine.rs:9-14).
 #pragma once
+#include <sys/mman.h>
 #include <cstdint>
 #include <cstdlib>
 #include <mutex>
@@ -35,7 +36,17 @@ public:
     ~TriArray() { std::free(p_); }
     void resize_uninit(size_t n) {
         std::free(p_); p_ = nullptr; n_ = 0;
-        if (n) { p_ = static_cast<Triangle*>(std::malloc(n * sizeof(Triangle))); if (!p_) throw std::bad_alloc(); }
+        if (n) {
+            // Large arrays on transparent huge pages where the kernel offers them: the parallel writers fault every page in, and 224 MB is 55 000
+            // small pages (taken one at a time under the address-space lock) or 107 large ones.
+            const size_t bytes = n * sizeof(Triangle), huge = (size_t)2 << 20;
+            if (bytes >= 4 * huge) {
+                void* q = nullptr;
+                if (posix_memalign(&q, huge, (bytes + huge - 1) / huge * huge) != 0) throw std::bad_alloc();
+                (void)madvise(q, (bytes + huge - 1) / huge * huge, MADV_HUGEPAGE);
+                p_ = static_cast<Triangle*>(q);
+            } else { p_ = static_cast<Triangle*>(std::malloc(bytes)); if (!p_) throw std::bad_alloc(); }
+        }
         n_ = n;
     }
     size_t size() const { return n_; }
