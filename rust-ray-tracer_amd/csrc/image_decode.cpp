@@ -140,8 +140,22 @@ template <class Reader> inline int decode_block(Reader& br, const Huff& dct, con
 }
 
 // IJG "islow" inverse DCT: Loeffler-Ligtenberg-Moschytz, CONST_BITS = 13, PASS1_BITS = 2.
-inline int32_t descale(int32_t x, int n) { return (x + (1 << (n - 1))) >> n; }
 inline uint8_t clamp255(int32_t x) { return x < 0 ? 0 : x > 255 ? 255 : (uint8_t)x; }
+
+// 32-bit arithmetic that wraps: on the coefficients of a real picture nothing here comes near 2^31, but a hostile file can drive the sums past it, and
+// signed overflow is undefined where libjpeg's INT32 code merely produces garbage.  Same bits as int32_t arithmetic whenever that is defined.
+struct Wrap32 {
+    uint32_t u;
+    Wrap32() = default;
+    Wrap32(int32_t v) : u((uint32_t)v) {}
+    int32_t s() const { return (int32_t)u; }
+    friend Wrap32 operator+(Wrap32 a, Wrap32 b) { Wrap32 r; r.u = a.u + b.u; return r; }
+    friend Wrap32 operator-(Wrap32 a, Wrap32 b) { Wrap32 r; r.u = a.u - b.u; return r; }
+    friend Wrap32 operator*(Wrap32 a, Wrap32 b) { Wrap32 r; r.u = a.u * b.u; return r; }
+    Wrap32& operator+=(Wrap32 b) { u += b.u; return *this; }
+    Wrap32& operator*=(Wrap32 b) { u *= b.u; return *this; }
+};
+inline int32_t descale(Wrap32 x, int n) { return (Wrap32(1 << (n - 1)) + x).s() >> n; }
 
 void idct_islow(const int32_t in[64], uint8_t* out, size_t stride) {
     constexpr int CB = 13, P1 = 2;
@@ -150,26 +164,26 @@ void idct_islow(const int32_t in[64], uint8_t* out, size_t stride) {
     int32_t ws[64];
     for (int pass = 0; pass < 2; pass++) {
         for (int i = 0; i < 8; i++) {
-            int32_t s[8];
+            Wrap32 s[8];
             if (pass == 0) for (int k = 0; k < 8; k++) s[k] = in[8 * k + i];      // columns
             else           for (int k = 0; k < 8; k++) s[k] = ws[8 * i + k];      // rows
-            int32_t z2 = s[2], z3 = s[6];
-            int32_t z1 = (z2 + z3) * F0_541;
-            int32_t tmp2 = z1 + z3 * (-F1_847);
-            int32_t tmp3 = z1 + z2 * F0_765;
-            int32_t tmp0 = (s[0] + s[4]) * (1 << CB);
-            int32_t tmp1 = (s[0] - s[4]) * (1 << CB);
-            int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+            Wrap32 z2 = s[2], z3 = s[6];
+            Wrap32 z1 = (z2 + z3) * F0_541;
+            Wrap32 tmp2 = z1 + z3 * (-F1_847);
+            Wrap32 tmp3 = z1 + z2 * F0_765;
+            Wrap32 tmp0 = (s[0] + s[4]) * (1 << CB);
+            Wrap32 tmp1 = (s[0] - s[4]) * (1 << CB);
+            Wrap32 tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
             tmp0 = s[7]; tmp1 = s[5]; tmp2 = s[3]; tmp3 = s[1];
-            z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2; int32_t z4 = tmp1 + tmp3;
-            int32_t z5 = (z3 + z4) * F1_175;
+            z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2; Wrap32 z4 = tmp1 + tmp3;
+            Wrap32 z5 = (z3 + z4) * F1_175;
             tmp0 *= F0_298; tmp1 *= F2_053; tmp2 *= F3_072; tmp3 *= F1_501;
             z1 *= -F0_899; z2 *= -F2_562; z3 *= -F1_961; z4 *= -F0_390;
             z3 += z5; z4 += z5;
             tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
-            int32_t r[8] = {tmp10 + tmp3, tmp11 + tmp2, tmp12 + tmp1, tmp13 + tmp0, tmp13 - tmp0, tmp12 - tmp1, tmp11 - tmp2, tmp10 - tmp3};
+            Wrap32 r[8] = {tmp10 + tmp3, tmp11 + tmp2, tmp12 + tmp1, tmp13 + tmp0, tmp13 - tmp0, tmp12 - tmp1, tmp11 - tmp2, tmp10 - tmp3};
             if (pass == 0) for (int k = 0; k < 8; k++) ws[8 * k + i] = descale(r[k], CB - P1);
-            else           for (int k = 0; k < 8; k++) out[stride * i + k] = clamp255(descale(r[k], CB + P1 + 3) + 128);
+            else           for (int k = 0; k < 8; k++) out[stride * i + k] = clamp255((Wrap32(descale(r[k], CB + P1 + 3)) + 128).s());
         }
     }
 }
