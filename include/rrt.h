@@ -10,6 +10,9 @@
  * negative rrt_status; nothing aborts or unwinds across the boundary (the reference panics instead:
  * main.rs:24,28; utils.rs:61,85,170,184,193,222,275,347-349).  All input pointers are borrowed for the
  * duration of the call only; the library copies what it keeps.  One caller thread per handle.
+ * Host-side set-up work (parsing, texture decode, staging copies) runs on a process-wide pool of worker threads that the library creates on demand and keeps
+ * (RRT_HOST_THREADS caps a stage's share of it; with LOCAL_WORLD_SIZE / WORLD_SIZE set, the hardware threads are divided among the ranks of the node); the
+ * workers live until the process ends, so the library must not be unloaded (dlclose) while the process runs.  The frame path (rrt_render*) uses no host threads.
  *
  * There is NO CPU fallback in this library: every compute entry point runs hand-written HIP kernels on
  * gfx950 and fails with RRT_ERR_NO_DEVICE / RRT_ERR_HIP when no GPU is usable.
