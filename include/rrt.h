@@ -12,7 +12,7 @@
  * duration of the call only; the library copies what it keeps.  One caller thread per handle.
  * Host-side set-up work (parsing, texture decode, staging copies) runs on a process-wide pool of worker threads that the library creates on demand and keeps
  * (RRT_HOST_THREADS caps a stage's share of it; with LOCAL_WORLD_SIZE / WORLD_SIZE set, the hardware threads are divided among the ranks of the node); the
- * workers live until the process ends, so the library must not be unloaded (dlclose) while the process runs.  The frame path (rrt_render*) uses no host threads.
+ * workers live until the process ends, so the library must not be unloaded (dlclose) while the process runs.  Tracing itself uses no host threads; rrt_render into a pageable buffer copies the frame out of the staging ring on the pool.
  *
  * There is NO CPU fallback in this library: every compute entry point runs hand-written HIP kernels on
  * gfx950 and fails with RRT_ERR_NO_DEVICE / RRT_ERR_HIP when no GPU is usable.
