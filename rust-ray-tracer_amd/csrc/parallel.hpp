@@ -1,5 +1,5 @@
 // parallel.hpp -- the host side's only threading primitives: a blocking parallel_for over [0, n) and a single task beside the caller's own work.
-// Used by the once-per-scene set-up stages (parse, texture decode, triangle boxes, own-list index, staging copies); the frame path has no host threads.
+// Used by the once-per-scene set-up stages (parse, texture decode, triangle boxes, own-list index, staging copies -- the copy-out of a frame rendered into a pageable host buffer included; tracing itself has no host threads).
 //
 // Work runs on a process-wide pool of workers that is grown on demand and never torn down: creating a thread costs 30-60 us and threads of one
 // process are created one at a time (they share the address-space lock), so the ~500 short-lived threads of a six-texture scene load -- six decoders,
