@@ -167,6 +167,24 @@ def test_config3_tile_partition_4k(rrt, teapot):
     assert np.array_equal(fb.cpu().numpy().view(np.uint32), full)
 
 
+def test_config4_tile_partition_with_the_xcd_aware_block_order(rrt, soup1m):
+    """configs[4]'s partition: the 8 ranks' tile buffers of the 1 M-triangle soup -- a scene large enough for the XCD-aware block order (render.hip:
+    render_kernel, FrameParams::xcd_chunk), which re-labels the blocks of a launch -- rendered in turn on this GPU at 1920x1080 (8 100 local tiles per rank:
+    whole chunks plus a tail), gathered and de-tiled: the single-launch frame bit for bit; and a size whose launch is smaller than one round of chunks."""
+    torch = pytest.importorskip("torch")
+    sd, rt, osc, lights = soup1m
+    for w, h, world in ((1920, 1080, 8), (200, 120, 3)):
+        full = rt.render(w, h)
+        tpr = rrt.tiles_per_rank(w, h, world)
+        gathered = torch.empty((world, tpr * 64), dtype=torch.int32, device="cuda")
+        for r in range(world):
+            rt.render_tiles_into(gathered[r], w, h, r, world)
+        fb = torch.empty((h, w), dtype=torch.int32, device="cuda")
+        rt.detile_into(gathered, fb, w, h, world)
+        torch.cuda.synchronize()
+        assert np.array_equal(fb.cpu().numpy().view(np.uint32), full), (w, h, world)
+
+
 def test_config4_soup1m_4k(rrt, soup1m):
     """configs[4] on one GPU: 1 M-triangle soup @3840x2160 (root list of 10 961 straddlers -> group records, clusters.cpp)."""
     sd, rt, osc, lights = soup1m
