@@ -134,6 +134,8 @@ def test_config2_soup100k_1080p(rrt, soup100k):
     assert np.array_equal(exact.render(w, h), a), "default (indexed) frame differs from the reference-order (no_cull) frame"
     for mode in ("lane", "bundle", "ray"):
         assert np.array_equal(rrt.RayTracer(sd, lights, box_filter=mode).render(w, h), a), mode
+    # the reference's progressive display (50-row bands, engine.rs:196-253): band launches under the XCD-aware block order (a large scene) give the same frame
+    assert np.array_equal(rt.render_progressive(w, h, chunk_rows=50), a)
 
 
 def test_config3_teapot_4k(rrt, teapot, teapot_oracle):
