@@ -665,6 +665,7 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
     constexpr bool kLeaf = !kBundle;   // leaf children are tested at their parent by the lane-filter kernel only (measured: the extra code costs the bundle kernel 12 % on the teapot)
     bool done = !active;
     uint32_t cur = 0;        // node this lane has to enter next
+    uint32_t crank = 0;      // position of `cur` among its parent's sorted children (0 = the nearest): tie-break of the pick below
     uint32_t sp = 0;         // number of frames on this lane's stack == depth of `cur`
 #ifdef RRT_PREFETCH_NODES
     // Node records come through dependent SCALAR loads at the start of every visit, and on the soups most of them miss the L2 (140 k nodes x 96 B):
@@ -736,14 +737,20 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
 #define RRT_WAVE_FOOTPRINT 0
 #endif
 #ifndef RRT_PICK_POLICY
-#define RRT_PICK_POLICY 3
+#define RRT_PICK_POLICY 5
 #endif
 #ifndef RRT_PICK_POLICY_BUNDLE
 #define RRT_PICK_POLICY_BUNDLE 0   /* the bundle-filter kernel (coherent frames) is insensitive to the order: 0.868 ms either way; it keeps the rounds-1-2 pick */
 #endif
         constexpr int kPick = kBundle ? RRT_PICK_POLICY_BUNDLE : RRT_PICK_POLICY;
         uint32_t unode;
-        if constexpr (kPick == 3) {
+        if constexpr (kPick == 5) {
+            // deepest pending lane first; among those the lane that has come least far through its parent's sorted children (its node is the nearer one: lanes that
+            // finish it may still move on to the farther ones, never back), then the smaller id.  23 bits of the id in the key: larger scenes only lose the last tie-break.
+            const uint32_t key = done ? 0xFFFFFFFFu : (((63u - sp) << 26) | (crank << 23) | (cur & 0x007FFFFFu));
+            const uint32_t kmin = wave_min_u32(key);
+            unode = (uint32_t)__builtin_amdgcn_readlane((int)cur, __builtin_ctzll(__builtin_amdgcn_ballot_w64(key == kmin)));
+        } else if constexpr (kPick == 3) {
             // deepest pending lane first, ties to the smaller id.  The key keeps 26 bits of the id; the node itself is read from a lane that holds the
             // winning key, so larger scenes only lose the tie-break (any pending lane's node is a valid pick).
             const uint32_t key = done ? 0xFFFFFFFFu : (((63u - sp) << 26) | (cur & 0x03FFFFFFu));
@@ -1092,7 +1099,7 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                         stk.meta(sp - 1) = m + (1u << 28);
                         const uint32_t fcw = stk.fc(sp - 1), k = (m >> (3u * cursor)) & 7u;
                         const uint32_t fcm = kLeaf ? S.fc_mask : 0xFFFFFFFFu;
-                        if (!(((fcw & ~fcm) >> (24u + k)) & 1u)) { cur = (fcw & fcm) + k; break; }
+                        if (!(((fcw & ~fcm) >> (24u + k)) & 1u)) { cur = (fcw & fcm) + k; crank = cursor; break; }
                         // a leaf child whose triangle this ray hits (tested at the parent, above): it returns Some(t, triangle) without a visit;
                         // a leaf's own record holds its dense slot in leaf_base (it has no children to describe)
                         ret_slot = ((const DevNode*)nodes)[(fcw & fcm) + k].leaf_base;
