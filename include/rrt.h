@@ -139,7 +139,8 @@ int rrt_model_get_octree(const rrt_model *m, double *aabb, uint32_t *first_child
 
 /* Build-owned JPEG / PNG decode to RGB8 (stands where `image::ImageReader::open().decode()` does, utils.rs:345-368).  JPEG: 8-bit Huffman,
  * sequential or progressive, 4:4:4 / 4:2:2 / 4:2:0, any number of scans, restart markers -- bit-equal to libjpeg (islow IDCT, fancy upsampling);
- * PNG: 8-bit RGB or palette of 1-8 bits, Adam7-interlaced or not.  Anything else, and anything that does not decode to 3 bytes per pixel (greyscale, alpha -- the reference walks
+ * PNG: 8-bit RGB or palette of 1-8 bits, Adam7-interlaced or not; BMP: uncompressed 24-bit or palette; TGA (by file name): 24-bit, plain or run-length coded.
+ * Anything else, and anything that does not decode to 3 bytes per pixel (greyscale, alpha -- the reference walks
  * `as_bytes().chunks(3)` whatever the colour type), is RRT_ERR_UNSUPPORTED.  *rgb is malloc'd; free with rrt_free. */
 int rrt_decode_image_file(const char *path, uint8_t **rgb, uint32_t *width, uint32_t *height);
 void rrt_free(void *p);

@@ -1,5 +1,5 @@
 // image_decode.cpp -- build-owned texture decode: Huffman JPEG (8-bit; sequential or progressive; 4:4:4, 4:2:2, 4:2:0 or greyscale; one scan
-// or many; restart markers) and PNG (8-bit samples or 1-8-bit palette, interlaced or not).  Stands where the reference calls the `image` crate
+// or many; restart markers), PNG (8-bit samples or 1-8-bit palette, interlaced or not), uncompressed BMP and 24-bit TGA.  Stands where the reference calls the `image` crate
 // (`ImageReader::open(..).decode()`, src/file_management/utils.rs:345-350; image 0.25.9 -> zune-jpeg 0.5.8 / png 0.18.0,
 // Cargo.lock).  Those crates are not in the reference tree, JPEG decoders are not bit-identical to one another and no
 // reference test pins decoded texels, so parity at this boundary is UNPINNED: the hot path's input is
@@ -15,6 +15,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <climits>
 #include <cstring>
 #include <memory>
 
@@ -799,12 +800,79 @@ void decode_png(const std::vector<uint8_t>& buf, std::vector<uint8_t>& out, uint
 
 }  // namespace
 
+// ===================================================================== BMP, TGA (the uncompressed formats an .mtl is likely to name besides JPEG and PNG)
+uint32_t le16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+uint32_t le32(const uint8_t* p) { return le16(p) | (le16(p + 2) << 16); }
+
+// Windows bitmap: BITMAPINFOHEADER family, uncompressed 24-bit BGR or 1/4/8-bit palette (-> RGB8, as the `image` crate expands them); rows bottom-up
+// unless the height is negative.  32-bit and compressed bitmaps do not decode to 3 bytes per pixel: refused.
+void decode_bmp(const std::vector<uint8_t>& buf, std::vector<uint8_t>& out, uint32_t& W, uint32_t& H, uint32_t& channels) {
+    if (buf.size() < 54) fail(RRT_ERR_PARSE, "Cannot decode texture file: truncated BMP");
+    const uint32_t data_off = le32(&buf[10]), hdr = le32(&buf[14]);
+    if (hdr < 40 || 14 + (size_t)hdr > buf.size()) fail(RRT_ERR_UNSUPPORTED, "BMP: unsupported header");
+    const int32_t w = (int32_t)le32(&buf[18]), h = (int32_t)le32(&buf[22]);
+    const uint32_t planes = le16(&buf[26]), bpp = le16(&buf[28]), comp = le32(&buf[30]); uint32_t n_pal = le32(&buf[46]);
+    if (planes != 1 || w <= 0 || h == 0 || h == INT32_MIN) fail(RRT_ERR_PARSE, "Cannot decode texture file: bad BMP header");
+    W = (uint32_t)w; H = (uint32_t)(h < 0 ? -h : h);
+    if (W > kMaxImageDim || H > kMaxImageDim) fail(RRT_ERR_PARSE, "Cannot decode texture file: BMP dimensions beyond the supported 65535 x 65535");
+    if (comp != 0 || !(bpp == 24 || bpp == 8 || bpp == 4 || bpp == 1)) fail(RRT_ERR_UNSUPPORTED, "BMP: only uncompressed 24-bit or palette bitmaps");
+    const size_t row = (((size_t)W * bpp + 31) / 32) * 4;
+    if ((size_t)data_off > buf.size() || row * H > buf.size() - data_off) fail(RRT_ERR_PARSE, "Cannot decode texture file: truncated BMP");
+    const uint8_t* pal = &buf[14 + hdr];
+    if (bpp <= 8) { if (n_pal == 0) n_pal = 1u << bpp; if (n_pal > 256 || 14 + (size_t)hdr + 4 * (size_t)n_pal > buf.size()) fail(RRT_ERR_PARSE, "Cannot decode texture file: bad BMP palette"); }
+    channels = 3; out.resize((size_t)W * H * 3);
+    for (uint32_t y = 0; y < H; y++) {
+        const uint8_t* s = &buf[data_off + row * (h < 0 ? y : H - 1 - y)];
+        uint8_t* o = &out[(size_t)y * W * 3];
+        for (uint32_t x = 0; x < W; x++) {
+            if (bpp == 24) { o[3 * x] = s[3 * x + 2]; o[3 * x + 1] = s[3 * x + 1]; o[3 * x + 2] = s[3 * x]; continue; }
+            const uint32_t idx = bpp == 8 ? s[x] : bpp == 4 ? (s[x >> 1] >> ((x & 1) ? 0 : 4)) & 15u : (s[x >> 3] >> (7 - (x & 7))) & 1u;
+            if (idx >= n_pal) fail(RRT_ERR_PARSE, "Cannot decode texture file: palette index out of range");
+            o[3 * x] = pal[4 * idx + 2]; o[3 * x + 1] = pal[4 * idx + 1]; o[3 * x + 2] = pal[4 * idx];
+        }
+    }
+}
+
+// Truevision TGA: true-colour 24-bit, plain (type 2) or run-length coded (type 10); rows bottom-up unless the descriptor says top-down.  Has no signature:
+// recognised by the file name, as the `image` crate does for ImageReader::open.
+void decode_tga(const std::vector<uint8_t>& buf, std::vector<uint8_t>& out, uint32_t& W, uint32_t& H, uint32_t& channels) {
+    if (buf.size() < 18) fail(RRT_ERR_PARSE, "Cannot decode texture file: truncated TGA");
+    const uint32_t id_len = buf[0], cmap_type = buf[1], type = buf[2], cmap_len = le16(&buf[5]), cmap_bits = buf[7], bpp = buf[16], desc = buf[17];
+    W = le16(&buf[12]); H = le16(&buf[14]);
+    if (W == 0 || H == 0) fail(RRT_ERR_PARSE, "Cannot decode texture file: bad TGA header");
+    if (!(type == 2 || type == 10) || bpp != 24 || (desc & 0x10)) fail(RRT_ERR_UNSUPPORTED, "TGA: only 24-bit true-colour images (plain or run-length coded)");
+    size_t at = 18 + (size_t)id_len + (cmap_type ? (size_t)cmap_len * ((cmap_bits + 7) / 8) : 0);
+    channels = 3; out.resize((size_t)W * H * 3);
+    const size_t n = (size_t)W * H;
+    const bool top_down = desc & 0x20;
+    auto put = [&](size_t k, const uint8_t* bgr) {
+        const size_t y = k / W, x = k % W;
+        uint8_t* o = &out[((top_down ? y : H - 1 - y) * W + x) * 3];
+        o[0] = bgr[2]; o[1] = bgr[1]; o[2] = bgr[0];
+    };
+    if (type == 2) {
+        if (at > buf.size() || n * 3 > buf.size() - at) fail(RRT_ERR_PARSE, "Cannot decode texture file: truncated TGA");
+        for (size_t k = 0; k < n; k++) put(k, &buf[at + 3 * k]);
+    } else {
+        for (size_t k = 0; k < n;) {
+            if (at >= buf.size()) fail(RRT_ERR_PARSE, "Cannot decode texture file: truncated TGA");
+            const uint32_t c = buf[at++], run = (c & 127u) + 1;
+            if (k + run > n) fail(RRT_ERR_PARSE, "Cannot decode texture file: TGA run past the end of the image");
+            if (c & 128u) { if (buf.size() - at < 3) fail(RRT_ERR_PARSE, "Cannot decode texture file: truncated TGA"); for (uint32_t r = 0; r < run; r++) put(k + r, &buf[at]); at += 3; }
+            else { if (buf.size() - at < 3 * (size_t)run) fail(RRT_ERR_PARSE, "Cannot decode texture file: truncated TGA"); for (uint32_t r = 0; r < run; r++) put(k + r, &buf[at + 3 * r]); at += 3 * (size_t)run; }
+            k += run;
+        }
+    }
+}
+
 void decode_image_file(const std::string& path, std::vector<uint8_t>& bytes, uint32_t& width, uint32_t& height, uint32_t& channels) {
     std::vector<uint8_t> buf = slurp(path);
     static const uint8_t png_sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
     if (buf.size() >= 8 && !std::memcmp(buf.data(), png_sig, 8)) decode_png(buf, bytes, width, height, channels);
     else if (buf.size() >= 2 && buf[0] == 0xFF && buf[1] == 0xD8) decode_jpeg(buf, bytes, width, height, channels);
-    else fail(RRT_ERR_UNSUPPORTED, "Cannot decode texture file (not JPEG/PNG): " + path);
+    else if (buf.size() >= 2 && buf[0] == 'B' && buf[1] == 'M') decode_bmp(buf, bytes, width, height, channels);
+    else if (path.size() >= 4 && (path.compare(path.size() - 4, 4, ".tga") == 0 || path.compare(path.size() - 4, 4, ".TGA") == 0)) decode_tga(buf, bytes, width, height, channels);
+    else fail(RRT_ERR_UNSUPPORTED, "Cannot decode texture file (not JPEG, PNG, BMP or TGA): " + path);
 }
 
 }  // namespace rrt

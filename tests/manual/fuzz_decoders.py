@@ -16,6 +16,10 @@ for kw in (dict(quality=80, subsampling=0), dict(quality=60, subsampling=2), dic
 for kw in (dict(), dict(interlace=True)):
     b = io.BytesIO(); Image.fromarray(img).save(b, "PNG", **kw); seeds.append(("png", b.getvalue()))
 b = io.BytesIO(); Image.fromarray(img).quantize(16).save(b, "PNG", bits=4); seeds.append(("png", b.getvalue()))
+b = io.BytesIO(); Image.fromarray(img).save(b, "BMP"); seeds.append(("bmp", b.getvalue()))
+b = io.BytesIO(); Image.fromarray(img).quantize(16).save(b, "BMP"); seeds.append(("bmp", b.getvalue()))
+for kw in (dict(), dict(compression="tga_rle")):
+    b = io.BytesIO(); Image.fromarray(img).save(b, "TGA", **kw); seeds.append(("tga", b.getvalue()))
 ok = err = 0
 os.environ["RRT_JPEG_PART_BYTES"] = "64"; os.environ["RRT_HOST_THREADS"] = "8"
 with tempfile.TemporaryDirectory() as d:

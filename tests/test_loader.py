@@ -325,6 +325,34 @@ def test_png_interlaced_and_low_bit_depth(rrt, tmp_path):
     assert e.value.status == rrt.ERR_UNSUPPORTED
 
 
+def test_bmp_and_tga_decoders(rrt, tmp_path):
+    """The uncompressed formats an .mtl may name besides JPEG and PNG: 24-bit and palette BMP (bottom-up rows, padded to 4 bytes), 24-bit TGA plain and
+    run-length coded, against PIL; 32-bit variants do not decode to 3 bytes per pixel (the reference's `chunks(3)` walk would garble them) and are refused."""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(31)
+    for h, w in ((1, 1), (3, 5), (7, 2), (16, 16), (37, 53)):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        img[:, : w // 2] = img[0, 0]                                   # runs for the RLE coder
+        p = tmp_path / "a.bmp"; Image.fromarray(img).save(p)
+        assert np.array_equal(rrt.decode_image_file(str(p)), img), ("bmp24", h, w)
+        for colors in (2, 16, 200):
+            Image.fromarray(img).quantize(colors).save(p)
+            assert np.array_equal(rrt.decode_image_file(str(p)), np.asarray(Image.open(p).convert("RGB"))), ("bmp palette", h, w, colors)
+        for rle in (False, True):
+            t = tmp_path / "a.tga"; Image.fromarray(img).save(t, compression="tga_rle" if rle else None)
+            assert np.array_equal(rrt.decode_image_file(str(t)), img), ("tga", h, w, rle)
+    rgba = np.dstack([img, np.full(img.shape[:2], 255, np.uint8)])
+    for name in ("b.bmp", "b.tga"):
+        q = tmp_path / name; Image.fromarray(rgba).save(q)
+        with pytest.raises(rrt.RrtError) as e:
+            rrt.decode_image_file(str(q))
+        assert e.value.status == rrt.ERR_UNSUPPORTED
+    data = open(tmp_path / "a.tga", "rb").read()
+    (tmp_path / "cut.tga").write_bytes(data[: len(data) // 2])
+    with pytest.raises(rrt.RrtError):
+        rrt.decode_image_file(str(tmp_path / "cut.tga"))
+
+
 def _write(tmp_path, obj_text, mtl_text="newmtl m\nKa 1 1 1\nmap_Ka t.png\n"):
     Image = pytest.importorskip("PIL.Image")
     Image.fromarray(np.full((2, 2, 3), 128, np.uint8)).save(tmp_path / "t.png")
