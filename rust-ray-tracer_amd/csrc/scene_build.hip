@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -52,6 +53,7 @@ inline unsigned grid_for(size_t n) { return (unsigned)((n + kBlock - 1) / kBlock
 // ------------------------------------------------------------------------------------------------ octree build
 struct Oct {
     const Triangle* tris; uint32_t n;
+    const double* pos;                  // the caller's position array [n][3][3] when the triangle records are not packed yet (rrt_raytracer_create_from_arrays), else null
     double* tbox;                       // [n][6] Aabb::from_triangle (aabb.rs:25-47)
     uint32_t* cur;                      // [n] node (temporary id) the triangle arrives at on the current level, kNone once it has settled / was dropped
     uint32_t* own;                      // [n] node (temporary id) whose `triangles` Vec holds it, kNone = outside the root (octree.rs:71-73)
@@ -116,10 +118,12 @@ __global__ void __launch_bounds__(kOctBlock) k_oct_init(Oct S) {
     LdsMerge M; M.begin(s_min, s_cnt, 0u, 1u);
     uint32_t n_act = 0;
     for (uint32_t t = blockIdx.x * kOctBlock + threadIdx.x; t < S.n; t += gridDim.x * kOctBlock) {
-        const Triangle& T = S.tris[t];
+        double v[9];
+        if (S.pos) { for (int k = 0; k < 9; k++) v[k] = S.pos[9 * (size_t)t + k]; }
+        else { const Triangle& T = S.tris[t]; v[0] = T.v1.x; v[1] = T.v1.y; v[2] = T.v1.z; v[3] = T.v2.x; v[4] = T.v2.y; v[5] = T.v2.z; v[6] = T.v3.x; v[7] = T.v3.y; v[8] = T.v3.z; }
         // Aabb::from_triangle, aabb.rs:25-47 (f64::min/max == fmin/fmax)
-        const double lo[3] = {fmin(T.v1.x, fmin(T.v2.x, T.v3.x)), fmin(T.v1.y, fmin(T.v2.y, T.v3.y)), fmin(T.v1.z, fmin(T.v2.z, T.v3.z))};
-        const double hi[3] = {fmax(T.v1.x, fmax(T.v2.x, T.v3.x)), fmax(T.v1.y, fmax(T.v2.y, T.v3.y)), fmax(T.v1.z, fmax(T.v2.z, T.v3.z))};
+        const double lo[3] = {fmin(v[0], fmin(v[3], v[6])), fmin(v[1], fmin(v[4], v[7])), fmin(v[2], fmin(v[5], v[8]))};
+        const double hi[3] = {fmax(v[0], fmax(v[3], v[6])), fmax(v[1], fmax(v[4], v[7])), fmax(v[2], fmax(v[5], v[8]))};
         bool touch = true;                                       // Aabb::intersects, aabb.rs:49-60 (inclusive)
         for (int k = 0; k < 3; k++) { S.tbox[6 * (size_t)t + k] = lo[k]; S.tbox[6 * (size_t)t + 3 + k] = hi[k]; if (hi[k] < S.rlo[k] || lo[k] > S.rhi[k]) touch = false; }
         S.cur[t] = touch ? 0u : kNone; S.own[t] = kNone; S.trig[t] = 0u;
@@ -733,17 +737,31 @@ void gpu_build_scene(const TriSource& src, uint32_t n, const Box& root, bool ena
     HB_TRY(hipEventRecord(evs[0], st));
     Triangle* d_tris = A1.take<Triangle>(n);
     if (src.tris) staged_upload(d_tris, src.tris, sizeof(Triangle) * (size_t)n, st);
-    else if (n) {
-        double* d_pos = A1.take<double>(9 * (size_t)n), *d_uv = A1.take<double>(9 * (size_t)n), *d_nrm = A1.take<double>(9 * (size_t)n); uint32_t* d_mat = A1.take<uint32_t>(n);
-        staged_upload(d_pos, src.pos, 72 * (size_t)n, st); staged_upload(d_uv, src.uv, 72 * (size_t)n, st); staged_upload(d_nrm, src.nrm, 72 * (size_t)n, st); staged_upload(d_mat, src.mat, 4 * (size_t)n, st);
-        hipLaunchKernelGGL(k_pack_triangles, dim3(grid_for(n)), dim3(kBlock), 0, st, d_pos, d_uv, d_nrm, d_mat, n, d_tris);
+    // The caller's own arrays: the octree needs the positions only, so they go up first and the tree is built while the other two thirds (texture
+    // coordinates, normals, materials) follow on the upload stream, on a pool thread; the triangle records are packed when the index needs them.
+    double* d_pos = nullptr, *d_uv = nullptr, *d_nrm = nullptr; uint32_t* d_mat = nullptr;
+    hipEvent_t ev_attr = nullptr;
+    struct EvOne { hipEvent_t& e; ~EvOne() { if (e) (void)hipEventDestroy(e); } } ev_attr_guard{ev_attr};
+    std::unique_ptr<AsyncTask> attr_task;
+    if (!src.tris && n) {
+        d_pos = A1.take<double>(9 * (size_t)n); d_uv = A1.take<double>(9 * (size_t)n); d_nrm = A1.take<double>(9 * (size_t)n); d_mat = A1.take<uint32_t>(n);
+        staged_upload(d_pos, src.pos, 72 * (size_t)n, st);
+        HB_TRY(hipEventCreateWithFlags(&ev_attr, hipEventDisableTiming));
+        hipStream_t st2 = (hipStream_t)upload_stream();
+        int dev = 0;
+        HB_TRY(hipGetDevice(&dev));
+        attr_task.reset(new AsyncTask([=, &src] {
+            HB_TRY(hipSetDevice(dev));                                  // (HIP's current device is per thread, and a pool worker keeps its last one)
+            staged_upload(d_uv, src.uv, 72 * (size_t)n, st2); staged_upload(d_nrm, src.nrm, 72 * (size_t)n, st2); staged_upload(d_mat, src.mat, 4 * (size_t)n, st2);
+            HB_TRY(hipEventRecord(ev_attr, st2));
+        }));
     }
     HB_TRY(hipEventRecord(evs[1], st));
     if (after_upload) after_upload();
     lap("triangle upload (pinned staging)");
 
     Oct S{};
-    S.tris = d_tris; S.n = n;
+    S.tris = d_tris; S.n = n; S.pos = d_pos;
     S.tbox = A1.take<double>(6 * (size_t)n); S.cur = A1.take<uint32_t>(n); S.own = A1.take<uint32_t>(n); S.trig = A1.take<uint32_t>(n + 1);
     S.nbox = A1.take<double>(6 * cap); S.first = A1.take<uint32_t>(cap); S.second = A1.take<uint32_t>(cap); S.cnt = A1.take<uint32_t>(cap); S.child_base = A1.take<uint32_t>(cap);
     S.block_parent = A1.take<uint32_t>(cap / 8 + 1);
@@ -902,6 +920,11 @@ void gpu_build_scene(const TriSource& src, uint32_t n, const Box& root, bool ena
         hipLaunchKernelGGL(k_idx_scatter, dim3(grid_for(n_in)), dim3(kBlock), 0, st, X, flip);
     }
     hipLaunchKernelGGL(k_idx_leaf_slots, dim3(grid_for(n_nodes)), dim3(kBlock), 0, st, X);
+    if (attr_task) {                                                   // the records are needed from here on (k_idx_slots, k_suspects)
+        attr_task->wait();
+        HB_TRY(hipStreamWaitEvent(st, ev_attr, 0));
+        hipLaunchKernelGGL(k_pack_triangles, dim3(grid_for(n)), dim3(kBlock), 0, st, d_pos, d_uv, d_nrm, d_mat, n, d_tris);
+    }
     hipLaunchKernelGGL(k_idx_slots, dim3(grid_for((size_t)n_slots_total + 8)), dim3(kBlock), 0, st, X);
     hipLaunchKernelGGL(k_idx_clusters, dim3(grid_for((size_t)n_cl + 8)), dim3(kBlock), 0, st, X);
     if (n_cl) hipLaunchKernelGGL(k_idx_supers, dim3(grid_for(n_cl)), dim3(kBlock), 0, st, X);
