@@ -29,6 +29,7 @@ struct rrt_raytracer {
     std::vector<void*> allocs;       // every hipMalloc of this raytracer
     void* arena = nullptr; size_t arena_bytes = 0, arena_used = 0;   // the scene's buffers (one allocation)
     uint64_t scene_bytes = 0;
+    bool all_inside_root = false;    // no triangle of the tree pokes out of the root box (then a child's subtree box lies inside its octant box: render.hip's certain-hit test)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     rrt_stats stats{};
     bool stats_pending = false;
@@ -576,6 +577,24 @@ void setup_on_host(rrt_raytracer* rt, const Model& M, rrt_vec3 origin, const rrt
         const double org[3] = {origin.x, origin.y, origin.z};
         if (!(o.flags & RRT_FLAG_NO_CULL)) find_origin_suspects(M, org, CS.pad, sus);
         rt->n_suspects = (uint32_t)sus.size();
+        {   // does any triangle of the tree poke out of the root box?  (NaN coordinates count as poking out)
+            std::atomic<int> out_of_root{0};
+            const Triangle* tr = M.triangles.data();
+            parallel_ranges(M.triangles.size(), 1 << 14, [&](size_t b, size_t e, size_t) {
+                for (size_t i = b; i < e && !out_of_root.load(std::memory_order_relaxed); i++) {
+                    const Vec3* v[3] = {&tr[i].v1, &tr[i].v2, &tr[i].v3};
+                    double lo[3], hi[3];
+                    for (int a = 0; a < 3; a++) {
+                        const double c[3] = {a == 0 ? v[0]->x : a == 1 ? v[0]->y : v[0]->z, a == 0 ? v[1]->x : a == 1 ? v[1]->y : v[1]->z, a == 0 ? v[2]->x : a == 1 ? v[2]->y : v[2]->z};
+                        lo[a] = std::fmin(c[0], std::fmin(c[1], c[2])); hi[a] = std::fmax(c[0], std::fmax(c[1], c[2]));
+                    }
+                    bool touch = true, inside = true;
+                    for (int a = 0; a < 3; a++) { if (hi[a] < M.root.lo[a] || lo[a] > M.root.hi[a]) touch = false; if (!(lo[a] >= M.root.lo[a] && hi[a] <= M.root.hi[a])) inside = false; }
+                    if (touch && !inside) out_of_root.store(1, std::memory_order_relaxed);
+                }
+            });
+            rt->all_inside_root = out_of_root.load() == 0;
+        }
         if (sus.size() > RRT_MAX_SUSPECTS) sus.resize(1);              // beyond the cap every ray from the origin runs unfiltered; the list is not read
         S.suspects = upload(rt, sus.data(), sus.size());               keep(kBufSuspects, S.suspects, sus.size() * sizeof(DevSuspect));
     }
@@ -647,6 +666,7 @@ void setup_on_gpu(rrt_raytracer* rt, const TriSource& src, uint32_t n_tris, cons
     S.has_groups = G.has_groups; S.bounds_plain = G.bounds_plain;
     S.cull_limit = (float)(G.scene_magnitude * 4.0);
     rt->n_suspects = G.n_suspects;
+    rt->all_inside_root = G.all_inside_root != 0;
     // small tables go through the same stream
     {
         void* d_m = static_cast<char*>(rt->arena) + rt->arena_used; rt->arena_used += (mats.size() * sizeof(DevMaterial) + 255) & ~(size_t)255;
@@ -699,6 +719,7 @@ int create_raytracer(const rrt_light* lights, uint32_t n_lights, rrt_vec3 origin
     DevScene& S = rt->scene;
     S.cull_enabled = (o.flags & RRT_FLAG_NO_CULL) ? 0u : 1u;
     S.cull_half_over_limit = S.cull_limit > 0.0f ? 0.5f / S.cull_limit : 0.0f;
+    S.inner_shrink = (S.cull_enabled && (rt->all_inside_root || std::getenv("RRT_FORCE_CERTAIN_HIT") /* developer: shows what the flag guards against */) && !std::getenv("RRT_NO_CERTAIN_HIT")) ? (float)((double)S.cull_limit / 4.0 / 32768.0 * 2.0) : 0.0f;   // 2 x pad (clusters.cpp: kPadFraction); render.hip, single-candidate child test
     S.n_suspects = rt->n_suspects;
     S.n_lights = n_lights; S.max_reflection_depth = o.max_reflection_depth; S.stack_levels = max_depth > 1 ? max_depth - 1 : 1;   // (stack_levels: only internal nodes push a frame; the deepest level holds leaves)
     S.origin[0] = origin.x; S.origin[1] = origin.y; S.origin[2] = origin.z;

@@ -85,6 +85,7 @@ struct DevScene {                // passed to kernels by value (kernarg segment 
     uint32_t has_groups;         // some own list carries group records (clusters.cpp): launches use the kernel instantiation that handles them
     uint32_t n_suspects;         // triangles whose plane passes through `origin` (see DevSuspect); more than RRT_MAX_SUSPECTS: every ray from `origin` runs unfiltered
     const DevSuspect* suspects;
+    float inner_shrink;          // 2 x the filter's pad when every triangle of the tree lies inside the root box (a child's subtree box then lies inside its octant box), else 0: render.hip, RRT_CERTAIN_HIT
     uint32_t bounds_plain;       // every node plane (lo, mid, hi) is 0 or has magnitude in [2^-200, 2^200]: the walk may share the reciprocal of a ray's direction across its slab quotients (render.hip, RayRcp)
     DevLight lights[RRT_MAX_LIGHTS];
 #ifdef RRT_PROFILE

@@ -124,8 +124,9 @@ __global__ void __launch_bounds__(kOctBlock) k_oct_init(Oct S) {
         // Aabb::from_triangle, aabb.rs:25-47 (f64::min/max == fmin/fmax)
         const double lo[3] = {fmin(v[0], fmin(v[3], v[6])), fmin(v[1], fmin(v[4], v[7])), fmin(v[2], fmin(v[5], v[8]))};
         const double hi[3] = {fmax(v[0], fmax(v[3], v[6])), fmax(v[1], fmax(v[4], v[7])), fmax(v[2], fmax(v[5], v[8]))};
-        bool touch = true;                                       // Aabb::intersects, aabb.rs:49-60 (inclusive)
-        for (int k = 0; k < 3; k++) { S.tbox[6 * (size_t)t + k] = lo[k]; S.tbox[6 * (size_t)t + 3 + k] = hi[k]; if (hi[k] < S.rlo[k] || lo[k] > S.rhi[k]) touch = false; }
+        bool touch = true, inside = true;                        // Aabb::intersects, aabb.rs:49-60 (inclusive)
+        for (int k = 0; k < 3; k++) { S.tbox[6 * (size_t)t + k] = lo[k]; S.tbox[6 * (size_t)t + 3 + k] = hi[k]; if (hi[k] < S.rlo[k] || lo[k] > S.rhi[k]) touch = false; if (!(lo[k] >= S.rlo[k] && hi[k] <= S.rhi[k])) inside = false; }
+        if (touch && !inside) S.ctr[2] = 1u;                      // a triangle of the tree pokes out of the root box (any number of writers, one value)
         S.cur[t] = touch ? 0u : kNone; S.own[t] = kNone; S.trig[t] = 0u;
         if (touch) { atomicMin(&s_min[0], t); n_act++; }
     }
@@ -574,7 +575,7 @@ __global__ void __launch_bounds__(kBlock) k_pack_triangles(const double* __restr
 }
 __global__ void k_set_root(Oct S) {
     for (int a = 0; a < 3; a++) { S.nbox[a] = S.rlo[a]; S.nbox[3 + a] = S.rhi[a]; }
-    S.first[0] = kNone; S.second[0] = kNone; S.cnt[0] = 0u; S.child_base[0] = 0u; S.ctr[0] = 0u; S.ctr[1] = 0u;
+    S.first[0] = kNone; S.second[0] = kNone; S.cnt[0] = 0u; S.child_base[0] = 0u; S.ctr[0] = 0u; S.ctr[1] = 0u; S.ctr[2] = 0u;
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -783,8 +784,9 @@ void gpu_build_scene(const TriSource& src, uint32_t n, const Box& root, bool ena
     if (n) hipLaunchKernelGGL(k_oct_init, dim3(oct_grid), dim3(kOctBlock), 0, st, S);
     std::vector<uint32_t> level_begin{0u};
     uint32_t n_nodes = 1, lb = 0, le = 1, n_blocks = 0;
-    read_words(S.ctr, 2);
+    read_words(S.ctr, 3);
     uint32_t active = h_ctr[1];
+    out.all_inside_root = h_ctr[2] ? 0u : 1u;
     while (n && active) {
         hipLaunchKernelGGL(k_oct_second, dim3(oct_grid), dim3(kOctBlock), 0, st, S, lb, le);
         hipLaunchKernelGGL(k_oct_split, dim3(grid_for(le - lb)), dim3(kBlock), 0, st, S, lb, le);

@@ -24,7 +24,7 @@ struct GpuScene {
     uint32_t* oct_first_child = nullptr, *oct_tri_count = nullptr, *oct_own_off = nullptr /* n_nodes + 1 */, *oct_own_idx = nullptr /* n_in_tree */;
     uint32_t* slot_tri = nullptr, *slot_pos = nullptr;   // per device slot (tests)
     uint32_t n_nodes = 0, n_in_tree = 0, n_list_slots = 0, n_slots_total = 0, n_sup_records = 0, n_clusters = 0, max_depth = 0, max_own = 0;
-    uint32_t has_groups = 0, inline_leaves = 0, bounds_plain = 1, n_suspects = 0;
+    uint32_t has_groups = 0, inline_leaves = 0, bounds_plain = 1, n_suspects = 0, all_inside_root = 0;   // all_inside_root: no triangle of the tree pokes out of the root box
     double scene_magnitude = 0, pad = 0;
     double ms_upload = 0, ms_octree = 0, ms_index = 0;   // GPU time of the three stages (HIP events on the build stream)
 };

@@ -542,6 +542,46 @@ def test_direction_magnitude_does_not_matter_to_the_index(rrt, teapot, scale):
 
 
 @pytest.mark.gpu
+def test_triangles_poking_out_of_the_root_box(rrt, ob):
+    """The single-candidate shortcut of the bundle-filter kernel (render.hip: a ray that certainly crosses the child's shrunk SUBTREE box needs no f64 slab test
+    of the OCTANT box) relies on subtree boxes lying inside their octants, which fails when a triangle of the tree reaches beyond the root box: such scenes
+    must switch it off.  Scene: a small root, a wall of triangles inside it and slivers that stick out through its faces; rays that reach the slivers' outer
+    parts pass the root (and their child octant) by, so the reference does not find them there.  Frames of all variants against the oracle, bit for bit, from two
+    origins; the same scene shrunk to fit inside the root exercises the shortcut itself."""
+    rng = np.random.default_rng(77)
+    mats = [dict(ka=(1, 1, 1), kd=(1, 1, 1), ks=(0.3, 0.3, 0.3), ns=40.0, kr=0.0, tex=0, bump=-1)]
+    tex = [rng.integers(0, 256, (8, 8, 3), dtype=np.uint8)]
+    lights = rrt.default_lights()
+    lt = [(l.kind, l.intensity, (l.v.x, l.v.y, l.v.z)) for l in lights]
+    def scene(reach):
+        tris = []
+        for _ in range(400):                                            # a wall of small triangles inside the root
+            c = np.array([rng.uniform(-0.9, 0.9), rng.uniform(-0.9, 0.9), rng.uniform(-0.2, 0.9)])
+            tris.append(c + rng.uniform(-0.08, 0.08, (3, 3)))
+        for _ in range(60):                                             # slivers through the +x, -x and +y faces, each well inside one octant otherwise
+            y, z = rng.uniform(0.2, 0.8) * rng.choice([-1, 1]), rng.uniform(0.2, 0.8) * rng.choice([-1, 1])
+            side = rng.choice([-1.0, 1.0])
+            tris.append(np.array([[side * 0.6, y, z], [side * reach, y + 0.05, z], [side * reach, y - 0.05, z + 0.05]]))
+            x = rng.uniform(0.2, 0.8) * rng.choice([-1, 1])
+            tris.append(np.array([[x, 0.6, z], [x + 0.05, reach, z], [x - 0.05, reach, z + 0.05]]))
+        for sx, sy, sz in ((1, 1, 1), (-1, 1, 1), (1, -1, -1), (-1, -1, 1)):   # sails: inside one octant in y and z, far out of the root in x -- whole waves of rays cross only their outer part
+            tris.append(np.array([[sx * 0.6, sy * 0.5, sz * 0.5], [sx * reach * 1.2, sy * 0.1, sz * 0.9], [sx * reach * 1.2, sy * 0.9, sz * 0.1]]))
+        pos = np.ascontiguousarray(np.array(tris))
+        n = len(pos)
+        return pos, rng.random((n, 3, 3)), rng.normal(size=(n, 3, 3)), np.zeros(n, np.uint32)
+    root = (-1.0, 1.0, -1.0, 1.0, -1.0, 1.0)
+    for reach in (2.5, 0.95):
+        pos, uv, nrm, mat = scene(reach)
+        sd = rrt.SceneData.from_arrays(pos, uv, nrm, mat, mats, tex, root=root)
+        for origin in ((0.0, 0.0, -3.5), (1.5, 0.4, -3.0)):                # (inside the filter's range of 4 x the scene magnitude: farther origins switch the fp32 filters off altogether)
+            osc = ob.OracleScene(pos, uv, nrm, mat, mats, tex, lt, origin, root=root)
+            want, _ = osc.render(480, 360)
+            for mode in (None, "bundle", "lane", "ray"):
+                got = rrt.RayTracer(sd, lights, rrt.Vector3d(*origin), box_filter=mode).render(480, 360)
+                assert np.array_equal(got, want), (reach, origin, mode, int((got != want).sum()))
+        assert ((want != 0xFFFFFF) & (want != 0)).mean() > 0.02
+
+
 def test_bench_two_ranks_in_both_launch_modes_rehearsal():
     """bench.py --gpus 2 end to end with TWO rank processes (RRT_BENCH_REHEARSAL=1: both ranks on this box's one GPU, the collective over gloo -- RCCL refuses
     two ranks on one device; numbers from it are not results): (a) started plainly -- the GPU-free supervisor starts one torch.distributed.run per gather
