@@ -845,7 +845,7 @@ __device__ __forceinline__ void traverse(PROF_DECL const DevScene& S, const Stac
                                     CB.hx -= S.inner_shrink; CB.hy -= S.inner_shrink; CB.hz -= S.inner_shrink;
                                     const bool certain = lane_reach && r32.sigma > 0.0f && CB.hx >= 0.0f && CB.hy >= 0.0f && CB.hz >= 0.0f && slab32(CB, r32);
                                     need_exact = __builtin_amdgcn_ballot_w64(lane_reach && !certain) != 0ull;
-                                    PROF_ADD(13, need_exact ? 0 : 1);
+                                    PROF_ADD(5, need_exact ? 0 : 1);              // [5] single-candidate visits decided without the exact test
                                     if (!need_exact && lane_reach) { order = k; nchild = 1u; }
                                 }
                             }

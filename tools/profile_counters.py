@@ -19,7 +19,7 @@ buf = (C.c_uint64 * 24)()
 rt.render(W, H); L.rrt_prof_counters(rt._h, buf)       # warm + clear
 rt.render(W, H); ms = rt.last_stats()["kernel_ms"]; L.rrt_prof_counters(rt._h, buf)
 c = list(buf)
-names = ["node_visits(wave)", "node_visit_lanes", "tri_iters(wave)", "tri_lane_tests", "tri_box_tests(wave)", "5", "traverse_calls(wave)", "traverse_lanes", "slab_iters(wave)", "slab_lane_tests", "super_tests(wave)", "cluster_tests(wave)", "internal_visits(wave)", "shade_blocks(wave-divergent)", "slab_exact_fallbacks(wave)"]
+names = ["node_visits(wave)", "node_visit_lanes", "tri_iters(wave)", "tri_lane_tests", "tri_box_tests(wave)", "single_candidate_decided_in_fp32(wave)", "traverse_calls(wave)", "traverse_lanes", "slab_iters(wave)", "slab_lane_tests", "super_tests(wave)", "cluster_tests(wave)", "internal_visits(wave)", "shade_blocks(wave-divergent)", "slab_exact_fallbacks(wave)"]
 for i, n in enumerate(names):
     print(f"{n:24s} {c[i]:>16,d}")
 print(f"kernel_ms (counters build) {ms:.2f}")
