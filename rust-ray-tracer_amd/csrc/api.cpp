@@ -29,6 +29,7 @@ struct rrt_raytracer {
     std::vector<void*> allocs;       // every hipMalloc of this raytracer
     void* arena = nullptr; size_t arena_bytes = 0, arena_used = 0;   // the scene's buffers (one allocation)
     uint64_t scene_bytes = 0;
+    double filter_pad = 0;           // the pad the set-up gave the index's boxes (clusters.cpp / scene_build.hip: kPadFraction of the scene magnitude)
     bool all_inside_root = false;    // no triangle of the tree pokes out of the root box (then a child's subtree box lies inside its octant box: render.hip's certain-hit test)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     rrt_stats stats{};
@@ -593,7 +594,7 @@ void setup_on_host(rrt_raytracer* rt, const Model& M, rrt_vec3 origin, const rrt
                     if (touch && !inside) out_of_root.store(1, std::memory_order_relaxed);
                 }
             });
-            rt->all_inside_root = out_of_root.load() == 0;
+            rt->all_inside_root = out_of_root.load() == 0; rt->filter_pad = CS.pad;
         }
         if (sus.size() > RRT_MAX_SUSPECTS) sus.resize(1);              // beyond the cap every ray from the origin runs unfiltered; the list is not read
         S.suspects = upload(rt, sus.data(), sus.size());               keep(kBufSuspects, S.suspects, sus.size() * sizeof(DevSuspect));
@@ -666,7 +667,7 @@ void setup_on_gpu(rrt_raytracer* rt, const TriSource& src, uint32_t n_tris, cons
     S.has_groups = G.has_groups; S.bounds_plain = G.bounds_plain;
     S.cull_limit = (float)(G.scene_magnitude * 4.0);
     rt->n_suspects = G.n_suspects;
-    rt->all_inside_root = G.all_inside_root != 0;
+    rt->all_inside_root = G.all_inside_root != 0; rt->filter_pad = G.pad;
     // small tables go through the same stream
     {
         void* d_m = static_cast<char*>(rt->arena) + rt->arena_used; rt->arena_used += (mats.size() * sizeof(DevMaterial) + 255) & ~(size_t)255;
@@ -719,7 +720,7 @@ int create_raytracer(const rrt_light* lights, uint32_t n_lights, rrt_vec3 origin
     DevScene& S = rt->scene;
     S.cull_enabled = (o.flags & RRT_FLAG_NO_CULL) ? 0u : 1u;
     S.cull_half_over_limit = S.cull_limit > 0.0f ? 0.5f / S.cull_limit : 0.0f;
-    S.inner_shrink = (S.cull_enabled && (rt->all_inside_root || std::getenv("RRT_FORCE_CERTAIN_HIT") /* developer: shows what the flag guards against */) && !std::getenv("RRT_NO_CERTAIN_HIT")) ? (float)((double)S.cull_limit / 4.0 / 32768.0 * 2.0) : 0.0f;   // 2 x pad (clusters.cpp: kPadFraction); render.hip, single-candidate child test
+    S.inner_shrink = (S.cull_enabled && (rt->all_inside_root || std::getenv("RRT_FORCE_CERTAIN_HIT") /* developer: shows what the flag guards against */) && !std::getenv("RRT_NO_CERTAIN_HIT")) ? (float)(2.0 * rt->filter_pad) : 0.0f;   // 2 x the pad the boxes were built with; render.hip, single-candidate child test
     S.n_suspects = rt->n_suspects;
     S.n_lights = n_lights; S.max_reflection_depth = o.max_reflection_depth; S.stack_levels = max_depth > 1 ? max_depth - 1 : 1;   // (stack_levels: only internal nodes push a frame; the deepest level holds leaves)
     S.origin[0] = origin.x; S.origin[1] = origin.y; S.origin[2] = origin.z;
