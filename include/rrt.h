@@ -61,7 +61,7 @@ typedef struct { const uint8_t *rgb; uint32_t width, height; } rrt_texture;
 #define RRT_FLAG_NO_CULL 1u
 /* The index boxes are tested either by every ray against one box at a time (LANE filter) or by 64 boxes at a time against the wave's ray
  * bundle (BUNDLE filter; faster on coherent rays, slower on scattered ones).  Both give the same pixels.  By default the FIRST frame of a frame
- * size runs the variant a measured rule picks -- bundle filter above ~1300 primary rays per triangle of the scene, lane filter below
+ * size runs the variant a measured rule picks -- bundle filter above ~1200 primary rays per triangle of the scene, lane filter below
  * (profiles/r03_variant_sweep.json: right on 17 of 18 scene x size points, 5 % off on the other) -- so a host that renders one frame per run, as the
  * reference does, pays nothing for the choice; a SECOND frame of the same size is first rendered with every variant (a one-off stream
  * synchronisation), the fastest being kept for that size; these flags force one. */

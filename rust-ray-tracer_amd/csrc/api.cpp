@@ -195,7 +195,7 @@ void check_frame(const rrt_raytracer* rt, uint32_t width, uint32_t height) {
 
 // All traversal variants produce identical pixels; which is faster depends on how coherent the rays of a wave are (scene, camera, frame size).
 // The reference renders ONE frame per run, so the first frame of a size costs nothing extra: it runs the variant a measured rule picks (node-coherent
-// walk; bundle filter when the frame has more than ~1300 primary rays per triangle, lane filter below).  A caller that comes back for a SECOND
+// walk; bundle filter when the frame has more than ~1200 primary rays per triangle, lane filter below).  A caller that comes back for a SECOND
 // frame of the same size is rendering repeatedly, and that frame is first rendered with every variant (each twice: the first run warms caches) on the
 // caller's buffer and stream, timed with HIP events; the fastest is kept for that size.  This synchronises the stream once per size.
 void tune_variant(rrt_raytracer* rt, const FrameParams& f, uint32_t* d_out, void* stream) {
@@ -205,10 +205,10 @@ void tune_variant(rrt_raytracer* rt, const FrameParams& f, uint32_t* d_out, void
         rt->size_frames = 0; rt->size_measured = false;
         // First frame of a size (for a host that renders one frame per run, as the reference does, this IS the choice): the bundle filter pays once the
         // frame holds enough rays per triangle for a 4x4-pixel wave to stay inside few nodes and long lists -- measured over 3 models x 5 frame sizes
-        // and the 100 k soup (profiles/r03_variant_sweep.json: bundle wins at >= 1309 primary rays per triangle, 8-10 % faster; lane filter wins at
-        // <= 1279, by 17-96 %; one crossing, model.obj 640x480 at 1234, is mispredicted at a cost of 5 %).
+        // and the 100 k soup (profiles/r03_variant_sweep.json, re-measured with the final kernels: bundle wins at >= 1234 primary rays per triangle, by 4-12 %;
+        // lane filter wins at <= 719, by 12-180 %; nothing measured in between).
         const double rays_per_triangle = 4.0 * (double)f.width * (double)f.height / (double)(rt->scene.n_slots ? rt->scene.n_slots : 1u);
-        rt->walk = rays_per_triangle > 1300.0 ? 1 : 0;
+        rt->walk = rays_per_triangle > 1200.0 ? 1 : 0;
     }
     if (rt->size_measured) return;
     if (++rt->size_frames < 2) return;
