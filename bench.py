@@ -570,7 +570,9 @@ def main() -> None:
                     "frac": round(frac, 4) if frac else None, "traffic": traffic, "valu_issue_frac": round(valu_issue, 3) if valu_issue else None,
                     "kernel_ms": round(kernel_ms, 4),
                     "note": "achieved = f64 flop EXECUTED per launch (rocprofv3 SQ_INSTS_VALU_{ADD,MUL,FMA x2,TRANS}_F64 x 64 lanes) / live kernel time; peak = f64 vector peak with FMA, "
-                            "which the reference's unfused arithmetic (-ffp-contract=off, required for parity) can reach at most half of",
+                            "which the reference's unfused arithmetic (-ffp-contract=off, required for parity) can reach at most half of.  The fraction counts f64 work EXECUTED: "
+                            "removing f64 work that decides nothing lowers it while the frame gets faster (round 3: teapot 9.49 -> 7.01 GFLOP per frame, 0.873 -> 0.841 ms, "
+                            "0.139 -> 0.107; DESIGN.md section 4) -- valu_issue_frac beside it is the pipe's actual occupancy",
                     "executed": executed, "executed_unavailable_reason": prof_reason,
                     "hbm": {"algorithmic_bytes_per_launch": hbm_bytes, "achieved": round(hbm_bytes / (kernel_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBPS,
                             "unit": "GB/s", "frac": round(hbm_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6),
